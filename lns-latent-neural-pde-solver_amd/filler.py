@@ -1,0 +1,105 @@
+"""Deterministic, torch-RNG-independent synthetic weights and fields.
+
+There are no checkpoints or datasets in the build/bench environment, so every
+parity test, golden fixture and bench run uses "random-init" weights.  To make
+the SAME weights reproducible in three places (the reference import in the
+build container, the CPU oracle, and the HIP engine on the GPU box) the values
+are a pure function of (state_dict key, shape, seed): a counter-based
+splitmix64 hash mapped to a uniform variate.  Scales follow PyTorch's default
+initialisers (U(+-1/sqrt(fan_in)) for conv/linear) so a
+64..256-step rollout stays bounded.
+
+`zero_module` tensors of the conditional propagator
+(reference: modules/cond_utils.py:12-16, used at
+train_stage2_twophase_conditional.py:47-58) get NON-zero values here on
+purpose: at the reference's zero init the conditioning path has
+no effect and would be untested.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _fnv1a64(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for ch in s.encode("utf-8"):
+        h ^= ch
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = (x + _GOLD) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(tag: str, n: int, seed: int) -> np.ndarray:
+    """n float32 values in [0,1), a pure function of (tag, seed, index)."""
+    h0 = np.uint64((_fnv1a64(tag) ^ ((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)))
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * _GOLD + h0
+    z = _splitmix64(idx)
+    return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / (1 << 24))
+
+
+def normal(tag: str, shape, seed: int) -> np.ndarray:
+    """Approximately N(0,1) float32 field (sum of 4 uniforms, variance-matched)."""
+    n = int(np.prod(shape))
+    acc = np.zeros(n, dtype=np.float32)
+    for k in range(4):
+        acc += uniform01("%s#%d" % (tag, k), n, seed)
+    return ((acc - np.float32(2.0)) * np.float32(np.sqrt(3.0))).reshape(shape).astype(np.float32)
+
+
+def fill_tensor(key: str, shape, seed: int):
+    """Synthetic value for state_dict entry `key`; None => keep module default
+    (non-learned buffers such as rotary `inv_freq`)."""
+    shape = tuple(int(s) for s in shape)
+    if key.endswith("inv_freq"):
+        return None
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = uniform01(key, n, seed)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "pe":
+        v = (u * 2 - 1) * np.float32(0.035)
+    elif leaf in ("weights1", "weights2") and len(shape) == 5:
+        # spectral weights: scale * U[0,1)  (reference: modules/basics.py:118-124)
+        v = u * np.float32(1.0 / (shape[0] * shape[1]))
+    elif len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        v = (u * 2 - 1) * np.float32(1.0 / np.sqrt(fan_in))
+    elif leaf == "weight":          # norm scales
+        v = np.float32(1.0) + (u * 2 - 1) * np.float32(0.1)
+    else:                           # biases
+        v = (u * 2 - 1) * np.float32(0.05)
+    return v.reshape(shape).astype(np.float32)
+
+
+def fill_state_dict(shapes: dict, seed: int) -> dict:
+    """shapes: {key: shape}.  Returns {key: float32 ndarray} for every key that
+    the filler owns (buffers like inv_freq are omitted)."""
+    out = {}
+    for k, shp in shapes.items():
+        v = fill_tensor(k, shp, seed)
+        if v is not None:
+            out[k] = v
+    return out
+
+
+def load_into_torch_module(module, seed: int):
+    """Overwrite a torch module's parameters/buffers in place with the
+    deterministic filler (used on the reference model and on the drop-in)."""
+    import torch
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k, t in sd.items():
+            v = fill_tensor(k, tuple(t.shape), seed)
+            if v is not None:
+                t.copy_(torch.from_numpy(v).to(t.dtype))
+    return module

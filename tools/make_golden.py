@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs ONLY in the build container (needs /root/reference, imported on CPU through
+oracle/ref_shim.py).  The reference can not travel to the GPU box, so what is
+committed is DATA: for each case the preset name, seeds, and (sub-sampled)
+outputs of the reference's own `LatentDynamics.predict`
+(train_stage2_ns2d.py:143-158 and the SW / two-phase variants) in fp32 and in
+fp64 (`model.double()`), on deterministic synthetic weights
+(lns_amd.filler, a pure function of state_dict key/shape/seed) and inputs.
+
+    python tools/make_golden.py            # all cases
+    python tools/make_golden.py ns2d_mini  # one case
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ref_models  # noqa: E402
+from lns_amd import config, filler  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# name -> (preset, overrides, B, T, steps stored, spatial stride of stored fields)
+CASES = {
+    "ns2d_mini": ("ns2d_mini", {}, 2, 16, [1, 2, 4, 8, 16], 1),
+    "ns2d_mini_zeros": ("ns2d_mini", {"is_periodic": False}, 2, 4, [1, 4], 1),
+    "ns2d_mini_sa": ("ns2d_mini", {"use_fa": False}, 2, 4, [1, 4], 1),
+    "ns2d_mini_nocoarse": ("ns2d_mini", {"disable_coarse_attn": True}, 2, 4, [1, 4], 1),
+    "ns2d_mini_fourier": ("ns2d_mini", {"final_smoothing": True, "fourier_resolutions": [16],
+                                        "Ly": 64, "Lx": 64, "resolution": 64,
+                                        "latent_resolution": 8, "attn_resolutions": [16, 32]},
+                          2, 2, [1, 2], 2),
+    "ns2d_64": ("ns2d_64", {}, 2, 8, [1, 8], 2),
+    "ns2d_128": ("ns2d_128", {}, 2, 64, [1, 2, 4, 8, 16, 32, 64], 4),
+    "sw_half_periodic": ("sw_half_periodic", {}, 2, 16, [1, 4, 16], 4),
+    "sw_96x192x5": ("sw_96x192x5", {}, 2, 16, [1, 4, 16], 4),
+    "twophase": ("twophase", {}, 2, 8, [1, 8], 3),
+    "twophase_cond": ("twophase_cond", {}, 2, 16, [1, 4, 16], 3),
+}
+WEIGHT_SEED = 1
+INPUT_SEED = 7
+
+
+def make_inputs(args, B):
+    x = filler.normal("x", (B, args.in_channels, args.Ly, args.Lx), INPUT_SEED)
+    param = None
+    if args.family == "twophase_cond":
+        param = filler.uniform01("param", B, INPUT_SEED).astype(np.float32)
+    return x, param
+
+
+def run_reference(args, B, T, dtype):
+    model = ref_models.build_reference_dynamics(args, WEIGHT_SEED, dtype=dtype)
+    if dtype == torch.float64 and args.family == "twophase_cond":
+        # modules/cond_utils.py:34 casts the embedding to fp32 (`.float()`); the fp64
+        # tie-breaker run re-casts it (module attribute patched in memory, no source edit)
+        import ref_shim
+        mod = ref_shim.load_reference()["train_stage2_twophase_conditional"]
+        if not getattr(mod.fourier_embedding, "_lns_f64", False):
+            orig = mod.fourier_embedding
+
+            def fe64(t, dim, max_period=10000, _o=orig):
+                return _o(t, dim, max_period).to(t.dtype)
+            fe64._lns_f64 = True
+            mod.fourier_embedding = fe64
+    x, param = make_inputs(args, B)
+    xt = torch.from_numpy(x).to(dtype)
+    pt = torch.from_numpy(param).to(dtype) if param is not None else None
+    with torch.no_grad():
+        z0 = model.x_to_z(xt)
+        lat, dec = [], []
+        z = z0
+        for _ in range(T):
+            z = model.propagator(z, pt) if pt is not None else model.propagator(z)
+            lat.append(z)
+            dec.append(model.z_to_x(z))
+        lat = torch.stack(lat, 1)
+        dec = torch.stack(dec, 1)
+        # cross-check that the loop above IS predict()
+        y = model.predict(xt, min(T, 2), pt, to_x=True) if pt is not None else \
+            model.predict(xt, min(T, 2), to_x=True)
+        assert torch.equal(y, dec[:, : y.shape[1]]), "predict() != explicit loop"
+    return z0.numpy(), lat.numpy(), dec.numpy(), model
+
+
+def main(which):
+    os.makedirs(OUT, exist_ok=True)
+    for name in which:
+        preset, over, B, T, steps, sub = CASES[name]
+        args = config.preset(preset, **over)
+        t0 = time.time()
+        z0, lat, dec, model = run_reference(args, B, T, torch.float32)
+        z0d, latd, decd, _ = run_reference(args, B, T, torch.float64)
+        sidx = [s - 1 for s in steps]
+        nparam = sum(v.numel() for v in model.state_dict().values())
+        meta = dict(case=name, preset=preset, overrides=over, B=B, T=T, steps=steps, sub=sub,
+                    weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED,
+                    n_tensors=len(model.state_dict()), n_params=int(nparam),
+                    torch=torch.__version__,
+                    note="*_f64 arrays: computed by the reference in fp64, stored rounded to fp32; fields stored as y[:, steps-1, :, ::sub, ::sub]; norms over full fields")
+        arrays = dict(
+            meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+            z0=z0.astype(np.float32),
+            z0_f64=z0d.astype(np.float32),
+            lat=lat[:, sidx].astype(np.float32),
+            lat_f64=latd[:, sidx].astype(np.float32),
+            dec=dec[:, sidx][..., ::sub, ::sub].astype(np.float32),
+            dec_f64=decd[:, sidx][..., ::sub, ::sub].astype(np.float32),
+            # per-(b,t,c) L2 norm of every decoded frame, all T steps
+            dec_norm=np.sqrt((dec.astype(np.float64) ** 2).sum((-1, -2))),
+            dec_norm_f64=np.sqrt((decd ** 2).sum((-1, -2))),
+            # the reference's own fp32 noise: rel-L2 of fp32 vs fp64 per step
+            ref_self_err=np.sqrt(((dec - decd) ** 2).sum((0, 2, 3, 4)) / (decd ** 2).sum((0, 2, 3, 4))),
+        )
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        print("%-20s B=%d T=%d  %.1f KB  self-err@T=%.2e  (%.1fs)" % (
+            name, B, T, os.path.getsize(path) / 1024, arrays["ref_self_err"][-1], time.time() - t0))
+
+    # state_dict key/shape manifests (data: names and shapes only), one per case
+    man_path = os.path.join(OUT, "state_dict_manifest.json")
+    man = {}
+    if os.path.exists(man_path):
+        with open(man_path) as f:
+            man = json.load(f)
+    for name in which:
+        preset, over, _, _, _, _ = CASES[name]
+        args = config.preset(preset, **over)
+        model = ref_models.build_reference_dynamics(args, WEIGHT_SEED)
+        man[name] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(man_path, "w") as f:
+        json.dump(man, f, indent=0, sort_keys=False)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or list(CASES))

@@ -1,0 +1,194 @@
+/*
+ * lns.h -- C ABI of the MI355X-native LNS rollout engine (liblns_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of BaratiLab/LNS-Latent-Neural-PDE-Solver:
+ *     LatentDynamics.predict(x, steps[, param], to_x)      train_stage2_ns2d.py:143-158
+ *         = SimpleAutoencoder.encode                          modules/autoencoder2d.py:174-177
+ *         -> steps x ( SimpleCNN.forward                      train_stage2_ns2d.py:82-87
+ *                      ; SimpleAutoencoder.decode )           modules/autoencoder2d.py:179-182
+ * (and the SW / two-phase / conditional variants of the same three functions).
+ *
+ * The reference has NO FFI/plugin layer of its own (it is 100% Python/PyTorch,
+ * SURVEY.md F1), so there is no foreign interface to mirror symbol-for-symbol:
+ * each entry point below names the reference Python method it replaces.  The
+ * ABI is plain C: opaque handle, plain pointers and sizes, int status codes,
+ * no C++/torch types.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - all tensors are fp32, NCHW, contiguous unless a batch stride is given;
+ *   - `x`, `z`, `y`, `out`, `param`, `workspace` are DEVICE pointers owned by
+ *     the caller (e.g. torch `data_ptr()`); weights passed to lns_set_weight
+ *     are HOST pointers;
+ *   - `stream` is a hipStream_t (void*), e.g. torch.cuda.current_stream().cuda_stream;
+ *     calls are asynchronous with respect to the host;
+ *   - every function returns 0 on success, a negative LNS_E* code otherwise and
+ *     never throws; lns_last_error() gives the message;
+ *   - an engine handle is not thread-safe; use one handle per GPU.
+ *   - device memory is allocated only by lns_finalize_weights() (packed weights)
+ *     and lns_prepare() (per-shape launch plans: index maps / rotary tables);
+ *     the run calls use caller-provided workspace only.
+ */
+#ifndef LNS_H_
+#define LNS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LNS_ABI_VERSION 1
+#define LNS_MAX_STAGES 8
+#define LNS_MAX_KEY 160
+
+/* status codes */
+#define LNS_OK 0
+#define LNS_EINVAL (-1)     /* bad argument / unsupported configuration */
+#define LNS_ENOKEY (-2)     /* unknown state_dict key / shape mismatch   */
+#define LNS_ESTATE (-3)     /* call order (weights not finalized, ...)   */
+#define LNS_ENOMEM (-4)     /* workspace too small / device alloc failed */
+#define LNS_EHIP (-5)       /* HIP runtime error                         */
+
+/* autoencoder flavour: which reference file the AE follows */
+#define LNS_AE_NONE 0
+#define LNS_AE_SQUARE 1         /* modules/autoencoder2d.py                 */
+#define LNS_AE_NONSQUARED 2     /* modules/autoencoder2d_nonsquared.py      */
+#define LNS_AE_HALF_PERIODIC 3  /* modules/autoencoder2d_half_periodic.py   */
+
+/* propagator flavour */
+#define LNS_PROP_NONE 0
+#define LNS_PROP_PLAIN 1        /* SimpleCNN, train_stage2_{ns2d,SW,twophase}.py:56-87        */
+#define LNS_PROP_CONDITIONAL 2  /* SimpleCNN, train_stage2_twophase_conditional.py:78-121      */
+
+/* per-axis boundary handling of the 'same' convolutions */
+#define LNS_PAD_ZEROS 0
+#define LNS_PAD_CIRCULAR 1
+
+/* Flat mirror of the YAML keys the reference reads from `args`
+ * (modules/autoencoder2d.py:19-27,78-92; train_stage2_ns2d.py:94-104). */
+typedef struct lns_config {
+    int32_t abi_version;            /* = LNS_ABI_VERSION */
+    int32_t ae_kind;                /* LNS_AE_*   */
+    int32_t prop_kind;              /* LNS_PROP_* */
+    int32_t in_channels;
+    int32_t latent_dim;
+    int32_t Ly, Lx;                 /* output field size            */
+    int32_t res_h, res_w;           /* `resolution` / `resolutions` */
+    int32_t latent_resolution;
+    int32_t ae_pad_y, ae_pad_x;     /* LNS_PAD_* of AE convs (is_periodic / periodic_direction) */
+    int32_t n_encoder_channels;
+    int32_t encoder_channels[LNS_MAX_STAGES];
+    int32_t encoder_res_blocks;
+    int32_t use_attn_enc;
+    int32_t n_decoder_channels;
+    int32_t decoder_channels[LNS_MAX_STAGES];
+    int32_t decoder_res_blocks;
+    int32_t n_attn_resolutions;
+    int32_t attn_resolutions[LNS_MAX_STAGES];
+    int32_t n_fourier_resolutions;
+    int32_t fourier_resolutions[LNS_MAX_STAGES];
+    int32_t use_fa;
+    int32_t final_smoothing;
+    int32_t disable_coarse_attn;
+    int32_t attn_heads;
+    int32_t attn_dim;
+    float hw_ratio;                 /* nonsquared / half-periodic AEs */
+    int32_t prop_n_block;
+    int32_t prop_n_embd;
+    int32_t prop_dilation;
+    int32_t prop_pad_y, prop_pad_x; /* LNS_PAD_* of the propagator's 3x3 convs */
+    int32_t cond_emb_dim;           /* conditional propagator only */
+    char ae_prefix[32];             /* state_dict prefix of the AE: "vq_ae." / "ae." / "" */
+    char prop_prefix[32];           /* "propagator." / ""                                 */
+} lns_config;
+
+typedef struct lns_engine lns_engine;
+
+/* message of the last failed lns_create() on this thread */
+const char* lns_create_error(void);
+
+/* Build the layer program for `cfg` (replaces LatentDynamics.__init__ /
+ * SimpleAutoencoder.__init__ / SimpleCNN.__init__: train_stage2_ns2d.py:91-104,
+ * modules/autoencoder2d.py:161-167, train_stage2_ns2d.py:57-80).  No GPU needed. */
+int lns_create(const lns_config* cfg, lns_engine** out);
+void lns_destroy(lns_engine* e);
+const char* lns_last_error(const lns_engine* e);
+
+/* Parameter table = the reference's state_dict() keys and shapes. */
+int lns_num_params(const lns_engine* e);
+int lns_param_info(const lns_engine* e, int index, char* key, int key_capacity,
+                   int64_t* shape /* [8] */, int* ndim, int* is_buffer);
+
+/* load_state_dict(): copy one tensor (HOST pointer, fp32, contiguous). */
+int lns_set_weight(lns_engine* e, const char* key, const float* host_data,
+                   const int64_t* shape, int ndim);
+/* Repack all weights into kernel-native layout and upload to HIP device `device`. */
+int lns_finalize_weights(lns_engine* e, int device);
+
+/* Latent shape for the configured field size: z is [B, C, H, W]. */
+int lns_latent_shape(const lns_engine* e, int* C, int* H, int* W);
+
+/* Build (and cache) launch plans for batch B; returns the workspace bytes the run
+ * calls need for that batch through *workspace_bytes (may be NULL). */
+int lns_prepare(lns_engine* e, int B, size_t* workspace_bytes);
+
+/* SimpleAutoencoder.encode: x [B,Cin,Ly,Lx] -> z [B,latent_dim,h,w]. */
+int lns_encode(lns_engine* e, const float* x, int B, float* z,
+               void* workspace, size_t workspace_bytes, void* stream);
+/* SimpleAutoencoder.decode: z [B,latent_dim,h,w] -> y [B,Cin,Ly,Lx]. */
+int lns_decode(lns_engine* e, const float* z, int B, float* y,
+               void* workspace, size_t workspace_bytes, void* stream);
+/* SimpleCNN.forward: z_in [B,latent_dim,H,W] (+ param [B] or NULL) -> z_out (same shape). */
+int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, int H, int W,
+                  float* z_out, void* workspace, size_t workspace_bytes, void* stream);
+/* LatentDynamics.predict(x, T[, param], to_x): out is [B,T,Cin,Ly,Lx] if to_x else
+ * [B,T,latent_dim,h,w]; latents_out (nullable) additionally receives [B,T,latent_dim,h,w]. */
+int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T, int to_x,
+                float* out, float* latents_out, void* workspace, size_t workspace_bytes,
+                void* stream);
+
+/* ---- diagnostics -------------------------------------------------------- */
+/* Layer trace: when enabled the run calls synchronise after every reference
+ * module boundary and keep a host copy of its output (tests compare them with
+ * the oracle layer by layer).  Slow; never enable in production. */
+int lns_trace_enable(lns_engine* e, int on);
+int lns_trace_count(const lns_engine* e);
+int lns_trace_info(const lns_engine* e, int index, char* name, int name_capacity,
+                   int64_t* shape /* [4] */);
+int lns_trace_copy(const lns_engine* e, int index, float* host_out);
+
+/* Kernel-level timing: after a run call with timing enabled, per-kernel-class
+ * elapsed milliseconds measured with HIP events on the call's stream. */
+int lns_timing_enable(lns_engine* e, int on);
+int lns_timing_count(const lns_engine* e);
+int lns_timing_info(const lns_engine* e, int index, char* name, int name_capacity,
+                    double* total_ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- kernel-level entry points (unit tests of the HIP kernels) ---------- */
+/* General fused convolution (the implicit-GEMM MFMA kernel):
+ *   y = act_out( conv(act_in(x * scale + shift)) + bias + badd ) + residual
+ * x [B,Cin,Hin,Win] optionally nearest-resized to (Hv,Wv) before padding;
+ * w [Cout,Cin,k,k] HOST pointer; ss [B,Cin,2] device (scale,shift) or NULL;
+ * act: 0 none, 1 swish, 2 gelu.  tile_variant <0 = automatic. */
+int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv,
+                  const float* w_host, const float* bias_host, int Cout, int ksize, int stride,
+                  int dilation, int pad_t, int pad_b, int pad_l, int pad_r, int mode_y, int mode_x,
+                  const float* ss, int act_in, int act_out, const float* residual,
+                  const float* badd, float* y, int tile_variant, void* stream);
+/* GroupNorm statistics -> per-(b,c) (scale,shift) such that norm(x) = x*scale+shift. */
+int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, float eps,
+                           const float* gamma_host, const float* beta_host, const float* premul,
+                           float* ss, void* stream);
+/* softmax attention: qkv [B,3*heads*dim_head,n] channel-major -> o [B,heads*dim_head,n] */
+int lns_op_attention(const float* qkv, int B, int heads, int dim_head, int n, float scale,
+                     float* o, void* stream);
+/* FABlock2D core: for every channel plane P of u [B,heads*C,H,W]:
+ *   P <- instance_norm( Kx[b,h] . P . Ky[b,h]^T ), kx [B,heads,H,H], ky [B,heads,W,W] */
+int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, int heads, int C,
+                       int H, int W, float eps, int apply_instance_norm, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LNS_H_ */

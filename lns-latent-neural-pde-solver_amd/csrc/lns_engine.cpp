@@ -1,0 +1,1116 @@
+// LNS rollout engine: weight packing, launch planning, execution, C ABI.
+// Replaces (behind include/lns.h) the reference's
+//   LatentDynamics.predict            train_stage2_ns2d.py:143-158
+//   SimpleAutoencoder.encode/decode   modules/autoencoder2d.py:174-182
+//   SimpleCNN.forward                 train_stage2_ns2d.py:82-87
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <type_traits>
+
+#include "lns_engine.h"
+
+namespace lns {
+void build_model(lns_engine* e);
+
+static thread_local std::string g_create_error;
+
+static std::string fmt(const char* f, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t err__ = (call);                                                              \
+        if (err__ != hipSuccess) {                                                              \
+            (e)->err = fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
+            return LNS_EHIP;                                                                    \
+        }                                                                                       \
+    } while (0)
+
+static size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------
+// tagged pointers: (space+0) << 56 | byte offset ; resolved at launch time
+// ---------------------------------------------------------------------------
+static inline uint64_t tag(int space, size_t byte_off) { return ((uint64_t)space << 56) | (uint64_t)byte_off; }
+template <class T> static inline T* as_ptr(uint64_t t) { return reinterpret_cast<T*>(t); }
+
+struct Bases { char* b[16]; long bs[16]; };
+template <class T> static inline void fix(T*& p, const Bases& B) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    if (!v) return;
+    const int sp = (int)(v >> 56);
+    p = reinterpret_cast<T*>(B.b[sp] + (v & 0x00FFFFFFFFFFFFFFull));
+}
+static inline void fixbs(long& bs, const Bases& B) {
+    if (bs < 0) bs = B.bs[SP_EXT0 + (int)(-bs - 1)];
+}
+
+// ---------------------------------------------------------------------------
+// host helpers shared by the planner and the op-level test entry points
+// ---------------------------------------------------------------------------
+// legacy 'nearest': src = min(floor(dst*scale), in-1), scale = in/out in fp32 unless given
+// (F.interpolate(scale_factor=2.0) basics.py:296 -> scale 0.5; nn.Upsample(size) autoencoder2d.py:134)
+static int nearest_src(int dst, int in, int out, float scale) {
+    if (in == out) return dst;
+    const float sc = scale > 0.0f ? scale : (float)in / (float)out;
+    int s = (int)floorf((float)dst * sc);
+    return s < in - 1 ? s : in - 1;
+}
+
+// padded/virtual coordinate -> source index (or -1 = zero).  `len` entries.
+static void build_axis_map(std::vector<int>& out, int len, int in, int virt, float scale, int pad_lo, int pad_hi,
+                           int mode) {
+    out.resize(len);
+    for (int p = 0; p < len; ++p) {
+        int u = p - pad_lo;
+        int src = -1;
+        if (p < virt + pad_lo + pad_hi) {
+            if (u < 0 || u >= virt) {
+                if (mode == LNS_PAD_CIRCULAR) { u %= virt; if (u < 0) u += virt; }
+                else u = -1;
+            }
+            if (u >= 0) src = nearest_src(u, in, virt, scale);
+        }
+        out[p] = src;
+    }
+}
+
+// [Cout][Cin][k][k] slices -> [taps][Cin_pad][Cout_pad]
+static void pack_conv_weight(float* dst, const float* src, int cout_off, int cout, int cin, int k, int Cin_pad,
+                             int Cout_pad) {
+    const int taps = k * k;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t)
+                dst[((size_t)t * Cin_pad + ci) * Cout_pad + cout_off + co] = src[((size_t)co * cin + ci) * taps + t];
+}
+
+struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Hout, Wout; };
+
+static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
+                          int kc_log2, int Cout_pad, int force_variant) {
+    g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
+    g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
+    if (g.Hout <= 0 || g.Wout <= 0) return false;
+    std::vector<int> cands;
+    if (force_variant >= 0) cands = {force_variant};
+    else if (Cout <= 32) cands = {CV_S32};
+    else if (Cout <= 64) cands = {CV_L64, CV_M64, CV_S64};
+    else cands = {CV_L128, CV_M128, CV_S64};
+    static const int pref[] = {5, 6, 4, 7, 3, 8};   // log2 BW preference on ties: 32,64,16,128,8,256
+    bool found = false;
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+        const ConvVariantInfo vi = conv_variant_info(cands[ci]);
+        if (Cout_pad % vi.TM != 0) continue;
+        long best_cost = -1; int best_bw = -1;
+        for (int pi = 0; pi < 6; ++pi) {
+            const int lb = pref[pi];
+            const int BW = 1 << lb;
+            if (BW > vi.TN) continue;
+            const int BH = vi.TN / BW;
+            const long cost = (long)((g.Hout + BH - 1) / BH) * BH * ((g.Wout + BW - 1) / BW) * BW;
+            ConvArgs tmp;
+            memset(&tmp, 0, sizeof tmp);
+            tmp.kc_log2 = kc_log2; tmp.ks = k;
+            tmp.PH = (BH - 1) * stride + (k - 1) * dil + 1;
+            tmp.PW = (BW - 1) * stride + (k - 1) * dil + 1;
+            if (conv_lds_bytes(cands[ci], tmp) > 150 * 1024) continue;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bw = lb; }
+        }
+        if (best_bw < 0) continue;
+        const int BW = 1 << best_bw, BH = vi.TN / BW;
+        const int txn = (g.Wout + BW - 1) / BW, tyn = (g.Hout + BH - 1) / BH;
+        const long blocks = (long)B * txn * tyn * ((Cout + vi.TM - 1) / vi.TM);
+        g.variant = cands[ci]; g.bw_log2 = best_bw; g.tiles_x = txn; g.tiles_y = tyn;
+        g.cout_tiles = (Cout + vi.TM - 1) / vi.TM;
+        g.PH = (BH - 1) * stride + (k - 1) * dil + 1;
+        g.PW = (BW - 1) * stride + (k - 1) * dil + 1;
+        found = true;
+        if (blocks >= 512) break;
+    }
+    return found;
+}
+
+// ---------------------------------------------------------------------------
+// arena allocator for plan temporaries (offsets into the caller's workspace)
+// ---------------------------------------------------------------------------
+struct Arena {
+    std::vector<std::pair<size_t, size_t>> free_;   // (offset, size), sorted by offset
+    std::map<size_t, size_t> live;
+    size_t top = 0, high = 0, base = 0;
+    size_t alloc(size_t bytes) {
+        bytes = round_up_sz(std::max<size_t>(bytes, 256), 256);
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= bytes) {
+                const size_t off = free_[i].first;
+                if (free_[i].second == bytes) free_.erase(free_.begin() + i);
+                else { free_[i].first += bytes; free_[i].second -= bytes; }
+                live[off] = bytes;
+                return off;
+            }
+        const size_t off = top;
+        top += bytes;
+        high = std::max(high, top);
+        live[off] = bytes;
+        return off;
+    }
+    void release(size_t off) {
+        auto it = live.find(off);
+        if (it == live.end()) throw std::runtime_error("arena: double free");
+        size_t sz = it->second;
+        live.erase(it);
+        auto pos = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (size_t)0));
+        pos = free_.insert(pos, {off, sz});
+        size_t i = pos - free_.begin();
+        if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
+            free_[i].second += free_[i + 1].second;
+            free_.erase(free_.begin() + i + 1);
+        }
+        if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
+            free_[i - 1].second += free_[i].second;
+            free_.erase(free_.begin() + i);
+            --i;
+        }
+        if (free_[i].first + free_[i].second == top) { top = free_[i].first; free_.erase(free_.begin() + i); }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// planner
+// ---------------------------------------------------------------------------
+struct TRef {
+    uint64_t ptr = 0;      // tagged
+    long bs = 0;           // batch stride (floats); <0: ext slot sentinel
+    int C = 0, H = 0, W = 0;
+    bool owned = false;    // arena allocation
+    size_t ws_off = 0;
+    // pending (un-materialised) transforms consumed by the next conv
+    uint64_t ss = 0; size_t ss_off = 0; bool ss_owned = false;
+    int act = ACT_NONE;
+    int vH = 0, vW = 0; float sch = 0, scw = 0;   // virtual nearest resize
+    bool pending() const { return ss != 0 || act != ACT_NONE || vH != 0; }
+};
+
+enum { CLS_CONV3 = 0, CLS_CONV1, CLS_GN, CLS_LNPE, CLS_ATTN, CLS_FAPOOL, CLS_FARED, CLS_FALRK, CLS_FASAND, CLS_COND,
+       CLS_SPECTRAL, CLS_MISC, CLS_COUNT };
+static const char* kClsName[CLS_COUNT] = {"conv3x3_mfma", "conv1x1_mfma", "gn_stats", "ln_pe", "attention",
+                                          "fa_pool", "fa_reducer", "fa_lrk", "fa_sandwich", "cond_embed",
+                                          "spectral", "misc"};
+
+struct Planner {
+    lns_engine* e;
+    Plan* plan;
+    int B;
+    Arena arena;
+    Planner(lns_engine* e_, Plan* p, int B_) : e(e_), plan(p), B(B_) {}
+
+    uint64_t wt(size_t float_off) const { return tag(SP_WT, float_off * 4); }
+    uint64_t vecp(int id) const { return id < 0 ? 0 : wt(e->vecs[id].off); }
+    int vec_id(const std::string& key) const {
+        for (size_t i = 0; i < e->vecs.size(); ++i) if (e->vecs[i].key == key) return (int)i;
+        throw std::runtime_error("no vec pack for " + key);
+    }
+    TRef alloc_t(int C, int H, int W) {
+        TRef t;
+        t.C = C; t.H = H; t.W = W; t.bs = (long)C * H * W; t.owned = true;
+        t.ws_off = arena.alloc((size_t)B * C * H * W * 4);
+        t.ptr = tag(SP_WS, t.ws_off);
+        return t;
+    }
+    void free_t(TRef& t) {
+        if (t.owned) { arena.release(t.ws_off); t.owned = false; }
+        if (t.ss_owned) { arena.release(t.ss_off); t.ss_owned = false; t.ss = 0; }
+    }
+    uint64_t const_ints(const std::vector<int>& v) {
+        const size_t off = plan->consts_i.size();
+        plan->consts_i.insert(plan->consts_i.end(), v.begin(), v.end());
+        while (plan->consts_i.size() % 4) plan->consts_i.push_back(-1);
+        return tag(SP_CT, off * 4) | (1ull << 55);   // bit 55: int segment (resolved in finish())
+    }
+    uint64_t const_floats(const std::vector<float>& v) {
+        const size_t off = plan->consts_f.size();
+        plan->consts_f.insert(plan->consts_f.end(), v.begin(), v.end());
+        while (plan->consts_f.size() % 4) plan->consts_f.push_back(0.f);
+        return tag(SP_CT, off * 4) | (1ull << 54);   // bit 54: float segment
+    }
+    void trace(const std::string& name, const TRef& t) {
+        Op op;
+        op.type = OP_TRACE; op.name = name; op.cls = CLS_MISC;
+        op.t_ptr = t.ptr; op.t_bs = t.bs; op.tC = t.C; op.tH = t.H; op.tW = t.W;
+        plan->ops.push_back(op);
+    }
+
+    // GroupNorm statistics of a materialised tensor -> pending (scale, shift) on it
+    void emit_gn(TRef& x, int groups, float eps, int vg, int vb, uint64_t premul, const std::string& name) {
+        if (x.pending()) throw std::runtime_error("GroupNorm input must be materialised: " + name);
+        if (x.C % groups) throw std::runtime_error("channels not divisible by groups: " + name);
+        Op op;
+        op.type = OP_GNSTATS; op.name = name; op.cls = CLS_GN;
+        memset(&op.gn, 0, sizeof op.gn);
+        op.gn.x = as_ptr<const float>(x.ptr); op.gn.x_bs = x.bs; op.gn.C = x.C; op.gn.HW = x.H * x.W;
+        op.gn.groups = groups; op.gn.eps = eps;
+        op.gn.gamma = as_ptr<const float>(vecp(vg)); op.gn.beta = as_ptr<const float>(vecp(vb));
+        op.gn.premul = as_ptr<const float>(premul);
+        x.ss_off = arena.alloc((size_t)B * x.C * 2 * 4);
+        x.ss = tag(SP_WS, x.ss_off); x.ss_owned = true;
+        op.gn.ss = as_ptr<float>(x.ss); op.gn.B = B;
+        op.bytes = 2.0 * B * x.C * x.H * x.W * 4;
+        plan->ops.push_back(op);
+    }
+
+    // fused conv; consumes the pending transforms of `in`
+    TRef emit_conv(const TRef& in, int pack_id, int k, int stride, int dil, const int* pad, int my, int mx,
+                   int act_out, const TRef* res, uint64_t badd, const TRef* out_forced, const std::string& name) {
+        const ConvPack& pk = e->packs[pack_id];
+        if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
+        const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
+        ConvGeom g;
+        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1))
+            throw std::runtime_error("no conv tiling for " + name);
+        const ConvVariantInfo vi = conv_variant_info(g.variant);
+        const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
+        std::vector<int> rm, cm;
+        build_axis_map(rm, (g.tiles_y - 1) * BH * stride + g.PH, in.H, Hv, in.sch, pad[0], pad[1], my);
+        build_axis_map(cm, (g.tiles_x - 1) * BW * stride + g.PW, in.W, Wv, in.scw, pad[2], pad[3], mx);
+        TRef out;
+        if (out_forced) out = *out_forced;
+        else out = alloc_t(pk.cout, g.Hout, g.Wout);
+        if (out.C != pk.cout || out.H != g.Hout || out.W != g.Wout)
+            throw std::runtime_error(fmt("%s: output shape mismatch (%d,%d,%d) vs (%d,%d,%d)", name.c_str(), out.C, out.H,
+                                         out.W, pk.cout, g.Hout, g.Wout));
+        if (res && (res->C != out.C || res->H != out.H || res->W != out.W || res->pending()))
+            throw std::runtime_error("residual shape mismatch: " + name);
+        Op op;
+        op.type = OP_CONV; op.name = name; op.cls = k == 3 ? CLS_CONV3 : CLS_CONV1; op.variant = g.variant;
+        ConvArgs& a = op.conv;
+        memset(&a, 0, sizeof a);
+        a.x = as_ptr<const float>(in.ptr); a.x_bs = in.bs; a.Cin = in.C; a.Hin = in.H; a.Win = in.W;
+        a.w = as_ptr<const float>(wt(pk.w_off));
+        a.bias = pk.has_bias ? as_ptr<const float>(wt(pk.b_off)) : nullptr;
+        a.ss = as_ptr<const float>(in.ss);
+        a.act_in = in.act; a.act_out = act_out;
+        a.rowmap = as_ptr<const int>(const_ints(rm));
+        a.colmap = as_ptr<const int>(const_ints(cm));
+        a.y = as_ptr<float>(out.ptr); a.y_bs = out.bs; a.Cout = pk.cout; a.Hout = g.Hout; a.Wout = g.Wout;
+        if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
+        a.badd = as_ptr<const float>(badd);
+        a.ks = k; a.stride = stride; a.dil = dil;
+        a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = pk.kc_log2;
+        a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
+        a.PH = g.PH; a.PW = g.PW; a.B = B;
+        op.flops = 2.0 * B * g.Hout * g.Wout * (double)pk.cout * pk.cin * k * k;
+        op.bytes = 4.0 * B * ((double)in.C * in.H * in.W + (double)pk.cout * g.Hout * g.Wout * (res ? 2 : 1));
+        plan->ops.push_back(op);
+        return out;
+    }
+    TRef conv_same1(const TRef& in, int pack, int act_out, const TRef* res, const TRef* out_forced,
+                    const std::string& name) {
+        const int pad[4] = {0, 0, 0, 0};
+        return emit_conv(in, pack, 1, 1, 1, pad, 0, 0, act_out, res, 0, out_forced, name);
+    }
+    TRef conv_same3(const TRef& in, int pack, int dil, int my, int mx, int act_out, const TRef* res, uint64_t badd,
+                    const std::string& name) {
+        const int pad[4] = {dil, dil, dil, dil};
+        return emit_conv(in, pack, 3, 1, dil, pad, my, mx, act_out, res, badd, nullptr, name);
+    }
+
+    // ---- composite modules ----------------------------------------------------
+    TRef lower_res(const Layer& l, TRef x) {
+        if (x.pending()) throw std::runtime_error("ResidualBlock input must be materialised: " + l.name);
+        TRef skip = x;
+        bool skip_owned = false;
+        if (l.chup >= 0) { skip = conv_same1(x, l.chup, ACT_NONE, nullptr, nullptr, l.name + ".channel_up"); skip_owned = true; }
+        TRef xin = x; xin.owned = false;
+        emit_gn(xin, 32, 1e-6f, l.g1, l.b1, 0, l.name + ".gn1");
+        xin.act = ACT_SWISH;
+        TRef h1 = conv_same3(xin, l.conv1, 1, l.mode_y, l.mode_x, ACT_NONE, nullptr, 0, l.name + ".conv1");
+        free_t(xin);   // releases the stats buffer only (xin does not own x)
+        emit_gn(h1, 32, 1e-6f, l.g2, l.b2, 0, l.name + ".gn2");
+        h1.act = ACT_SWISH;
+        TRef out = conv_same3(h1, l.conv2, 1, l.mode_y, l.mode_x, ACT_NONE, &skip, 0, l.name + ".conv2");
+        free_t(h1);
+        if (skip_owned) free_t(skip);
+        return out;
+    }
+
+    TRef lower_sa(const Layer& l, TRef x) {
+        if (x.pending()) throw std::runtime_error("SABlock input must be materialised");
+        const int n = x.H * x.W, inner = l.heads * l.dim_head;
+        if (l.pe >= 0 && n > l.pe_len) throw std::runtime_error("SABlock: more tokens than positional table rows");
+        TRef h = alloc_t(x.C, x.H, x.W);
+        {
+            Op op;
+            op.type = OP_LNPE; op.name = l.name + ".ln_pe"; op.cls = CLS_LNPE;
+            memset(&op.ln, 0, sizeof op.ln);
+            op.ln.x = as_ptr<const float>(x.ptr); op.ln.x_bs = x.bs; op.ln.C = x.C; op.ln.n = n; op.ln.eps = 1e-5f;
+            op.ln.gamma = as_ptr<const float>(vecp(l.ln_g)); op.ln.beta = as_ptr<const float>(vecp(l.ln_b));
+            op.ln.pe_t = as_ptr<const float>(vecp(l.pe)); op.ln.pe_stride = l.pe_len;
+            op.ln.h = as_ptr<float>(h.ptr); op.ln.B = B;
+            op.bytes = 2.0 * B * x.C * n * 4;
+            plan->ops.push_back(op);
+        }
+        TRef qkv = conv_same1(h, l.qkv, ACT_NONE, nullptr, nullptr, l.name + ".qkv");
+        free_t(h);
+        TRef o = alloc_t(inner, x.H, x.W);
+        {
+            Op op;
+            op.type = OP_ATTN; op.name = l.name + ".attn"; op.cls = CLS_ATTN;
+            op.at.qkv = as_ptr<const float>(qkv.ptr); op.at.B = B; op.at.heads = l.heads; op.at.D = l.dim_head;
+            op.at.n = n; op.at.scale = (float)std::pow((double)l.dim_head, -0.5); op.at.o = as_ptr<float>(o.ptr);
+            op.flops = 4.0 * B * l.heads * (double)n * n * l.dim_head;
+            op.bytes = 4.0 * B * 4.0 * inner * n;
+            plan->ops.push_back(op);
+        }
+        free_t(qkv);
+        TRef out = conv_same1(o, l.proj, ACT_NONE, &x, nullptr, l.name + ".proj_out");
+        free_t(o);
+        return out;
+    }
+
+    // rotary table for LowRankKernel: pos = torch.linspace(0,1,n) (fp32 arithmetic of
+    // torch.linspace), t = pos * (scale/min_freq) = pos*64, freqs = t * inv_freq  (embedding.py:171-176)
+    uint64_t rotary_table(int n, const std::string& invf_key) {
+        const Param& p = e->params[e->pindex.at(invf_key)];
+        const int half = (int)p.numel();
+        std::vector<float> cs((size_t)n * half * 2);
+        const float step = n > 1 ? (1.0f - 0.0f) / (float)(n - 1) : 0.0f;
+        for (int i = 0; i < n; ++i) {
+            float pos = (i < n / 2) ? (0.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+            const float t = pos * 64.0f;
+            for (int d = 0; d < half; ++d) {
+                const float f = t * p.host[d];
+                cs[((size_t)i * half + d) * 2] = (float)std::cos((double)f);
+                cs[((size_t)i * half + d) * 2 + 1] = (float)std::sin((double)f);
+            }
+        }
+        return const_floats(cs);
+    }
+
+    TRef lower_fa(const Layer& l, TRef x) {
+        if (x.pending()) throw std::runtime_error("FABlock2D input must be materialised");
+        const int C = x.C, H = x.H, W = x.W, heads = l.heads, dh = l.dim_head, lat = l.fa_lat, DK = l.fa_dk;
+        TRef xin = x; xin.owned = false;
+        emit_gn(xin, 1, 1e-5f, l.fa_g, l.fa_b, 0, l.name + ".in_norm");
+        TRef uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj");
+        TRef v = conv_same1(xin, l.toin, ACT_NONE, nullptr, nullptr, l.name + ".to_in");
+        free_t(xin);
+        // axis pooling
+        const size_t mx_off = arena.alloc((size_t)B * H * C * 4), my_off = arena.alloc((size_t)B * W * C * 4);
+        {
+            Op op;
+            op.type = OP_FAPOOL; op.name = l.name + ".pool"; op.cls = CLS_FAPOOL;
+            op.fp.v = as_ptr<const float>(v.ptr); op.fp.B = B; op.fp.C = C; op.fp.H = H; op.fp.W = W;
+            op.fp.mx = as_ptr<float>(tag(SP_WS, mx_off)); op.fp.my = as_ptr<float>(tag(SP_WS, my_off));
+            op.bytes = 4.0 * B * C * H * W;
+            plan->ops.push_back(op);
+        }
+        free_t(v);
+        TRef ux = alloc_t(lat, 1, H), uy = alloc_t(lat, 1, W);
+        for (int ax = 0; ax < 2; ++ax) {
+            const int* r = ax == 0 ? l.rx : l.ry;
+            const int n = ax == 0 ? H : W;
+            Op op;
+            op.type = OP_FARED; op.name = l.name + (ax == 0 ? ".to_x" : ".to_y"); op.cls = CLS_FARED;
+            memset(&op.fr, 0, sizeof op.fr);
+            op.fr.m = as_ptr<const float>(tag(SP_WS, ax == 0 ? mx_off : my_off));
+            op.fr.rows = (long)B * n; op.fr.n = n; op.fr.C = C; op.fr.Hid = 2 * C; op.fr.Out = lat;
+            op.fr.win_t = as_ptr<const float>(vecp(r[0])); op.fr.ln_g = as_ptr<const float>(vecp(r[1]));
+            op.fr.ln_b = as_ptr<const float>(vecp(r[2])); op.fr.w1_t = as_ptr<const float>(vecp(r[3]));
+            op.fr.w2_t = as_ptr<const float>(vecp(r[4])); op.fr.b2 = as_ptr<const float>(vecp(r[5]));
+            op.fr.u = as_ptr<float>((ax == 0 ? ux : uy).ptr);
+            op.flops = 2.0 * B * n * ((double)C * C + 2.0 * C * C + 2.0 * C * lat);
+            plan->ops.push_back(op);
+        }
+        arena.release(mx_off); arena.release(my_off);
+        TRef qkx = conv_same1(ux, l.qkx, ACT_NONE, nullptr, nullptr, l.name + ".lrk_x.to_qk");
+        TRef qky = conv_same1(uy, l.qky, ACT_NONE, nullptr, nullptr, l.name + ".lrk_y.to_qk");
+        free_t(ux); free_t(uy);
+        const size_t kx_off = arena.alloc((size_t)B * heads * H * H * 4), ky_off = arena.alloc((size_t)B * heads * W * W * 4);
+        for (int ax = 0; ax < 2; ++ax) {
+            const int n = ax == 0 ? H : W;
+            Op op;
+            op.type = OP_FALRK; op.name = l.name + (ax == 0 ? ".lrk_x" : ".lrk_y"); op.cls = CLS_FALRK;
+            op.fl.qk = as_ptr<const float>((ax == 0 ? qkx : qky).ptr); op.fl.B = B; op.fl.heads = heads; op.fl.DK = DK;
+            op.fl.n = n; op.fl.cs = as_ptr<const float>(rotary_table(n, ax == 0 ? l.invf_x : l.invf_y));
+            op.fl.kmat = as_ptr<float>(tag(SP_WS, ax == 0 ? kx_off : ky_off));
+            op.flops = 2.0 * B * heads * (double)n * n * DK;
+            plan->ops.push_back(op);
+        }
+        free_t(qkx); free_t(qky);
+        {
+            Op op;
+            op.type = OP_FASAND; op.name = l.name + ".sandwich"; op.cls = CLS_FASAND;
+            op.fs.u = as_ptr<const float>(uphi.ptr); op.fs.kx = as_ptr<const float>(tag(SP_WS, kx_off));
+            op.fs.ky = as_ptr<const float>(tag(SP_WS, ky_off)); op.fs.B = B; op.fs.heads = heads; op.fs.C = dh;
+            op.fs.H = H; op.fs.W = W; op.fs.eps = 1e-5f; op.fs.instnorm = 1; op.fs.out = as_ptr<float>(uphi.ptr);
+            op.flops = 2.0 * B * heads * dh * ((double)H * W * W + (double)H * H * W);
+            op.bytes = 8.0 * B * heads * dh * H * W;
+            plan->ops.push_back(op);
+        }
+        arena.release(kx_off); arena.release(ky_off);
+        TRef t1 = conv_same1(uphi, l.out1, ACT_GELU, nullptr, nullptr, l.name + ".to_out.1");
+        free_t(uphi);
+        TRef out = conv_same1(t1, l.out3, ACT_NONE, &x, nullptr, l.name + ".to_out.3");
+        free_t(t1);
+        return out;
+    }
+
+    // DilatedResidualBlock: train_stage2_ns2d.py:25-53
+    TRef lower_propblock(const Layer& l, TRef x) {
+        TRef xin = x; xin.owned = false;
+        emit_gn(xin, 1, 1e-5f, l.p_g1, l.p_b1, 0, l.name + ".conv.0");
+        TRef h1 = conv_same3(xin, l.p_c1, 1, l.mode_y, l.mode_x, ACT_GELU, nullptr, 0, l.name + ".conv.1");
+        free_t(xin);
+        TRef h2 = conv_same3(h1, l.p_c3, l.dil, l.mode_y, l.mode_x, ACT_GELU, nullptr, 0, l.name + ".conv.3");
+        free_t(h1);
+        TRef x1 = conv_same3(h2, l.p_c5, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, l.name + ".conv.5");
+        free_t(h2);
+        TRef xin2 = x1; xin2.owned = false;
+        emit_gn(xin2, 1, 1e-5f, l.p_g2, l.p_b2, 0, l.name + ".ffn.0");
+        TRef f1 = conv_same1(xin2, l.p_f1, ACT_GELU, nullptr, nullptr, l.name + ".ffn.1");
+        free_t(xin2);
+        TRef out = conv_same1(f1, l.p_f3, ACT_NONE, &x1, nullptr, l.name + ".ffn.3");
+        free_t(f1); free_t(x1);
+        return out;
+    }
+
+    // sequential program ---------------------------------------------------------
+    void lower_sequence(const std::vector<Layer>& L, TRef in, const TRef& out_ext) {
+        TRef cur = in;
+        for (size_t i = 0; i < L.size(); ++i) {
+            const Layer& l = L[i];
+            const bool last = (i + 1 == L.size());
+            TRef nxt;
+            switch (l.type) {
+                case LT_CONV: {
+                    int act_out = ACT_NONE;
+                    size_t skip = 0;
+                    // conv -> Swish with no norm in between: fuse the activation into the epilogue
+                    if (!last && L[i + 1].type == LT_SWISH) { act_out = ACT_SWISH; skip = 1; }
+                    const bool is_last = (i + 1 + skip == L.size());
+                    nxt = emit_conv(cur, l.pack, l.k, l.stride, l.dil, l.pad, l.mode_y, l.mode_x, act_out, nullptr, 0,
+                                    is_last ? &out_ext : nullptr, l.name);
+                    free_t(cur);
+                    i += skip;
+                    if (!is_last) trace(l.name, nxt);
+                    break;
+                }
+                case LT_SWISH:
+                    if (cur.ss == 0 || cur.act != ACT_NONE) throw std::runtime_error("unfusable Swish at " + l.name);
+                    cur.act = ACT_SWISH;
+                    continue;
+                case LT_GN:
+                    emit_gn(cur, l.groups, l.eps, l.vg, l.vb, 0, l.name);
+                    continue;
+                case LT_UP2:
+                    if (cur.pending()) throw std::runtime_error("resize of a pending tensor");
+                    cur.vH = 2 * cur.H; cur.vW = 2 * cur.W; cur.sch = 0.5f; cur.scw = 0.5f;
+                    continue;
+                case LT_RESIZE:
+                    if (cur.pending()) throw std::runtime_error("resize of a pending tensor");
+                    if (l.outH != cur.H || l.outW != cur.W) { cur.vH = l.outH; cur.vW = l.outW; cur.sch = 0; cur.scw = 0; }
+                    continue;
+                case LT_RES: nxt = lower_res(l, cur); free_t(cur); trace(l.name, nxt); break;
+                case LT_SA: nxt = lower_sa(l, cur); free_t(cur); trace(l.name, nxt); break;
+                case LT_FA: nxt = lower_fa(l, cur); free_t(cur); trace(l.name, nxt); break;
+                case LT_PROPBLOCK: nxt = lower_propblock(l, cur); free_t(cur); trace(l.name, nxt); break;
+                default: throw std::runtime_error("layer type not supported by this build: " + l.name);
+            }
+            if (last && l.type != LT_CONV) throw std::runtime_error("program must end in a convolution");
+            cur = nxt;
+        }
+    }
+
+    void finish() {
+        // int constants first, then float constants, in one device blob
+        const size_t ibytes = plan->consts_i.size() * 4;
+        for (Op& op : plan->ops) {
+            auto rebase = [&](auto*& p) {
+                uint64_t v = reinterpret_cast<uint64_t>(p);
+                if ((v >> 56) != SP_CT) return;
+                const bool is_f = (v >> 54) & 1;
+                uint64_t off = v & 0x003FFFFFFFFFFFFFull;
+                if (is_f) off += ibytes;
+                p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(tag(SP_CT, off));
+            };
+            if (op.type == OP_CONV) { rebase(op.conv.rowmap); rebase(op.conv.colmap); }
+            if (op.type == OP_FALRK) rebase(op.fl.cs);
+        }
+        plan->arena_bytes = arena.high;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------
+static int finalize_weights(lns_engine* e, int device) {
+    for (const Param& p : e->params)
+        if (!p.is_set) { e->err = "weight not set: " + p.key; return LNS_ESTATE; }
+    size_t off = 0;
+    for (ConvPack& p : e->packs) {
+        p.w_off = off; off += round_up_sz((size_t)p.k * p.k * p.Cin_pad * p.Cout_pad, 64);
+        p.b_off = off; off += round_up_sz((size_t)p.Cout_pad, 64);
+    }
+    for (VecPack& v : e->vecs) { v.off = off; off += round_up_sz(v.count, 64); }
+    std::vector<float> host(off, 0.0f);
+    for (const ConvPack& p : e->packs) {
+        int co = 0;
+        for (size_t i = 0; i < p.wkeys.size(); ++i) {
+            const Param& w = e->params[e->pindex.at(p.wkeys[i])];
+            pack_conv_weight(host.data() + p.w_off, w.host.data(), co, p.couts[i], p.cin, p.k, p.Cin_pad, p.Cout_pad);
+            if (!p.bkeys[i].empty()) {
+                const Param& b = e->params[e->pindex.at(p.bkeys[i])];
+                memcpy(host.data() + p.b_off + co, b.host.data(), (size_t)p.couts[i] * 4);
+            }
+            co += p.couts[i];
+        }
+    }
+    for (const VecPack& v : e->vecs) {
+        const Param& p = e->params[e->pindex.at(v.key)];
+        float* dst = host.data() + v.off;
+        if (v.xform == VX_NONE) memcpy(dst, p.host.data(), v.count * 4);
+        else if (v.xform == VX_TRANSPOSE2D) {   // [out][in] -> [in][out]
+            const size_t rows = (size_t)p.shape[0], cols = v.count / rows;
+            for (size_t r = 0; r < rows; ++r)
+                for (size_t c = 0; c < cols; ++c) dst[c * rows + r] = p.host[r * cols + c];
+        } else if (v.xform == VX_PE_T) {        // [1][L][C] -> [C][L]
+            const size_t L = (size_t)p.shape[1], C = (size_t)p.shape[2];
+            for (size_t i = 0; i < L; ++i)
+                for (size_t c = 0; c < C; ++c) dst[c * L + i] = p.host[i * C + c];
+        }
+    }
+    HIPCHK(e, hipSetDevice(device));
+    HIPCHK(e, init_kernels());
+    if (e->d_weights) { hipFree(e->d_weights); e->d_weights = nullptr; }
+    HIPCHK(e, hipMalloc(reinterpret_cast<void**>(&e->d_weights), std::max<size_t>(off, 64) * 4));
+    HIPCHK(e, hipMemcpy(e->d_weights, host.data(), off * 4, hipMemcpyHostToDevice));
+    e->weights_floats = off;
+    e->device = device;
+    e->finalized = true;
+    // plans hold weight offsets only, but rotary tables depend on inv_freq: drop cached plans
+    for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans}) {
+        for (auto& kv : *m) if (kv.second.d_consts) hipFree(kv.second.d_consts);
+        m->clear();
+    }
+    return LNS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------
+static TRef ext_tensor(int slot, int C, int H, int W) {
+    TRef t;
+    t.ptr = tag(SP_EXT0 + slot, 0); t.bs = -(long)(slot + 1); t.C = C; t.H = H; t.W = W;
+    return t;
+}
+
+static int upload_consts(lns_engine* e, Plan& p) {
+    const size_t ib = p.consts_i.size() * 4, fb = p.consts_f.size() * 4;
+    if (ib + fb == 0) return LNS_OK;
+    HIPCHK(e, hipMalloc(&p.d_consts, ib + fb));
+    if (ib) HIPCHK(e, hipMemcpy(p.d_consts, p.consts_i.data(), ib, hipMemcpyHostToDevice));
+    if (fb) HIPCHK(e, hipMemcpy(static_cast<char*>(p.d_consts) + ib, p.consts_f.data(), fb, hipMemcpyHostToDevice));
+    return LNS_OK;
+}
+
+enum PlanKind { PK_ENC, PK_DEC, PK_PROP };
+
+static int get_plan(lns_engine* e, PlanKind kind, int B, int H, int W, Plan** out) {
+    auto& m = kind == PK_ENC ? e->enc_plans : (kind == PK_DEC ? e->dec_plans : e->prop_plans);
+    const long key = ((long)B << 32) | ((long)H << 16) | (long)W;
+    auto it = m.find(key);
+    if (it != m.end()) { *out = &it->second; return LNS_OK; }
+    if (!e->finalized) { e->err = "lns_finalize_weights must be called first"; return LNS_ESTATE; }
+    const lns_config& c = e->cfg;
+    Plan plan;
+    plan.B = B; plan.H = H; plan.W = W;
+    try {
+        Planner pl(e, &plan, B);
+        if (kind == PK_ENC) {
+            if (e->enc.empty()) throw std::runtime_error("engine has no autoencoder");
+            pl.lower_sequence(e->enc, ext_tensor(EX_IN, c.in_channels, c.Ly, c.Lx),
+                              ext_tensor(EX_OUT, e->lat_C, e->lat_H, e->lat_W));
+        } else if (kind == PK_DEC) {
+            if (e->dec.empty()) throw std::runtime_error("engine has no autoencoder");
+            pl.lower_sequence(e->dec, ext_tensor(EX_IN, e->lat_C, e->lat_H, e->lat_W),
+                              ext_tensor(EX_OUT, c.in_channels, c.Ly, c.Lx));
+        } else {
+            if (e->prop.empty()) throw std::runtime_error("engine has no propagator");
+            pl.lower_sequence(e->prop, ext_tensor(EX_IN, c.latent_dim, H, W), ext_tensor(EX_OUT, c.latent_dim, H, W));
+        }
+        pl.finish();
+    } catch (const std::exception& ex) {
+        e->err = ex.what();
+        return LNS_EINVAL;
+    }
+    int rc = upload_consts(e, plan);
+    if (rc) return rc;
+    auto res = m.emplace(key, std::move(plan));
+    *out = &res.first->second;
+    return LNS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------
+struct EvPair { hipEvent_t a, b; int cls; const Op* op; };
+
+struct Runner {
+    lns_engine* e;
+    hipStream_t stream;
+    std::vector<EvPair> evs;
+    Runner(lns_engine* e_, hipStream_t s) : e(e_), stream(s) {}
+
+    int run(const Plan& plan, const ExtT* ext, char* arena_base) {
+        Bases B;
+        memset(&B, 0, sizeof B);
+        B.b[SP_WS] = arena_base;
+        B.b[SP_WT] = reinterpret_cast<char*>(e->d_weights);
+        B.b[SP_CT] = static_cast<char*>(plan.d_consts);
+        for (int i = 0; i < EX_COUNT; ++i) {
+            B.b[SP_EXT0 + i] = const_cast<char*>(static_cast<const char*>(ext[i].ptr));
+            B.bs[SP_EXT0 + i] = ext[i].bs;
+        }
+        for (const Op& op : plan.ops) {
+            EvPair ev;
+            if (e->timing_on && op.type != OP_TRACE) {
+                HIPCHK(e, hipEventCreate(&ev.a));
+                HIPCHK(e, hipEventCreate(&ev.b));
+                ev.cls = op.cls; ev.op = &op;
+                HIPCHK(e, hipEventRecord(ev.a, stream));
+            }
+            hipError_t rc = hipSuccess;
+            switch (op.type) {
+                case OP_CONV: {
+                    ConvArgs a = op.conv;
+                    fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
+                    fix(a.y, B); fix(a.res, B); fix(a.badd, B);
+                    fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
+                    rc = launch_conv(op.variant, a, stream);
+                    break;
+                }
+                case OP_GNSTATS: {
+                    GnStatsArgs a = op.gn;
+                    fix(a.x, B); fix(a.gamma, B); fix(a.beta, B); fix(a.premul, B); fix(a.ss, B); fixbs(a.x_bs, B);
+                    rc = launch_gn_stats(a, stream);
+                    break;
+                }
+                case OP_LNPE: {
+                    LnPeArgs a = op.ln;
+                    fix(a.x, B); fix(a.gamma, B); fix(a.beta, B); fix(a.pe_t, B); fix(a.h, B); fixbs(a.x_bs, B);
+                    rc = launch_ln_pe(a, stream);
+                    break;
+                }
+                case OP_ATTN: { AttnArgs a = op.at; fix(a.qkv, B); fix(a.o, B); rc = launch_attention(a, stream); break; }
+                case OP_FAPOOL: { FaPoolArgs a = op.fp; fix(a.v, B); fix(a.mx, B); fix(a.my, B); rc = launch_fa_pool(a, stream); break; }
+                case OP_FARED: {
+                    FaReducerArgs a = op.fr;
+                    fix(a.m, B); fix(a.win_t, B); fix(a.ln_g, B); fix(a.ln_b, B); fix(a.w1_t, B); fix(a.w2_t, B);
+                    fix(a.b2, B); fix(a.u, B);
+                    rc = launch_fa_reducer(a, stream);
+                    break;
+                }
+                case OP_FALRK: { FaLrkArgs a = op.fl; fix(a.qk, B); fix(a.cs, B); fix(a.kmat, B); rc = launch_fa_lrk(a, stream); break; }
+                case OP_FASAND: {
+                    FaSandwichArgs a = op.fs;
+                    fix(a.u, B); fix(a.kx, B); fix(a.ky, B); fix(a.out, B);
+                    rc = launch_fa_sandwich(a, stream);
+                    break;
+                }
+                case OP_TRACE: {
+                    if (!e->trace_on) break;
+                    const float* p = as_ptr<const float>(op.t_ptr);
+                    long bs = op.t_bs;
+                    fix(p, B); fixbs(bs, B);
+                    HIPCHK(e, hipStreamSynchronize(stream));
+                    TraceRec r;
+                    r.name = op.name; r.B = plan.B; r.C = op.tC; r.H = op.tH; r.W = op.tW;
+                    const size_t per = (size_t)op.tC * op.tH * op.tW;
+                    r.data.resize(per * plan.B);
+                    for (int b = 0; b < plan.B; ++b)
+                        HIPCHK(e, hipMemcpy(r.data.data() + per * b, p + bs * b, per * 4, hipMemcpyDeviceToHost));
+                    e->trace.push_back(std::move(r));
+                    break;
+                }
+                default: e->err = "op not implemented: " + op.name; return LNS_EINVAL;
+            }
+            if (rc != hipSuccess) {
+                e->err = fmt("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(rc));
+                return LNS_EHIP;
+            }
+            if (e->timing_on && op.type != OP_TRACE) {
+                HIPCHK(e, hipEventRecord(ev.b, stream));
+                evs.push_back(ev);
+            }
+        }
+        return LNS_OK;
+    }
+
+    int finish() {
+        if (!e->timing_on || evs.empty()) return LNS_OK;
+        HIPCHK(e, hipStreamSynchronize(stream));
+        if (e->timing.empty()) {
+            e->timing.resize(CLS_COUNT);
+            for (int i = 0; i < CLS_COUNT; ++i) e->timing[i].name = kClsName[i];
+        }
+        for (EvPair& ev : evs) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, ev.a, ev.b);
+            TimeRec& t = e->timing[ev.cls];
+            t.ms += ms; t.launches += 1; t.flops += ev.op->flops; t.bytes += ev.op->bytes;
+            hipEventDestroy(ev.a); hipEventDestroy(ev.b);
+        }
+        evs.clear();
+        return LNS_OK;
+    }
+};
+
+// workspace layout: [ z ping | z pong | arena ]
+struct WsLayout { size_t z_bytes, arena_off, total; };
+
+static int ws_layout(lns_engine* e, int B, WsLayout* L) {
+    size_t arena = 0;
+    Plan* p;
+    int rc;
+    if (!e->enc.empty()) {
+        if ((rc = get_plan(e, PK_ENC, B, 0, 0, &p))) return rc;
+        arena = std::max(arena, p->arena_bytes);
+        if ((rc = get_plan(e, PK_DEC, B, 0, 0, &p))) return rc;
+        arena = std::max(arena, p->arena_bytes);
+    }
+    if (!e->prop.empty() && e->lat_H > 0) {
+        if ((rc = get_plan(e, PK_PROP, B, e->lat_H, e->lat_W, &p))) return rc;
+        arena = std::max(arena, p->arena_bytes);
+    }
+    L->z_bytes = round_up_sz((size_t)B * std::max(1, e->lat_C) * std::max(1, e->lat_H) * std::max(1, e->lat_W) * 4, 256);
+    L->arena_off = 2 * L->z_bytes;
+    L->total = L->arena_off + arena + 256;
+    return LNS_OK;
+}
+
+}  // namespace lns
+
+using namespace lns;
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char* lns_create_error(void) { return g_create_error.c_str(); }
+
+int lns_create(const lns_config* cfg, lns_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return LNS_EINVAL; }
+    if (cfg->abi_version != LNS_ABI_VERSION) { g_create_error = "ABI version mismatch"; return LNS_EINVAL; }
+    lns_engine* e = new lns_engine();
+    e->cfg = *cfg;
+    e->cfg.ae_prefix[sizeof(e->cfg.ae_prefix) - 1] = 0;
+    e->cfg.prop_prefix[sizeof(e->cfg.prop_prefix) - 1] = 0;
+    try {
+        build_model(e);
+    } catch (const std::exception& ex) {
+        g_create_error = ex.what();
+        delete e;
+        return LNS_EINVAL;
+    }
+    *out = e;
+    return LNS_OK;
+}
+
+void lns_destroy(lns_engine* e) {
+    if (!e) return;
+    for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans})
+        for (auto& kv : *m) if (kv.second.d_consts) hipFree(kv.second.d_consts);
+    if (e->d_weights) hipFree(e->d_weights);
+    delete e;
+}
+
+const char* lns_last_error(const lns_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int lns_num_params(const lns_engine* e) { return e ? (int)e->params.size() : LNS_EINVAL; }
+
+int lns_param_info(const lns_engine* e, int index, char* key, int key_capacity, int64_t* shape, int* ndim,
+                   int* is_buffer) {
+    if (!e || index < 0 || index >= (int)e->params.size()) return LNS_EINVAL;
+    const Param& p = e->params[index];
+    if (key && key_capacity > 0) { strncpy(key, p.key.c_str(), key_capacity - 1); key[key_capacity - 1] = 0; }
+    if (shape) for (size_t i = 0; i < p.shape.size() && i < 8; ++i) shape[i] = p.shape[i];
+    if (ndim) *ndim = (int)p.shape.size();
+    if (is_buffer) *is_buffer = p.is_buffer ? 1 : 0;
+    return LNS_OK;
+}
+
+int lns_set_weight(lns_engine* e, const char* key, const float* host_data, const int64_t* shape, int ndim) {
+    if (!e || !key || !host_data) return LNS_EINVAL;
+    auto it = e->pindex.find(key);
+    if (it == e->pindex.end()) { e->err = std::string("unexpected key in state_dict: ") + key; return LNS_ENOKEY; }
+    Param& p = e->params[it->second];
+    if (shape) {
+        bool ok = (ndim == (int)p.shape.size());
+        for (int i = 0; ok && i < ndim; ++i) ok = (shape[i] == p.shape[i]);
+        if (!ok) { e->err = std::string("size mismatch for ") + key; return LNS_ENOKEY; }
+    }
+    p.host.assign(host_data, host_data + p.numel());
+    p.is_set = true;
+    e->finalized = false;
+    return LNS_OK;
+}
+
+int lns_finalize_weights(lns_engine* e, int device) {
+    if (!e) return LNS_EINVAL;
+    return finalize_weights(e, device);
+}
+
+int lns_latent_shape(const lns_engine* e, int* C, int* H, int* W) {
+    if (!e || e->enc.empty()) return LNS_EINVAL;
+    if (C) *C = e->lat_C;
+    if (H) *H = e->lat_H;
+    if (W) *W = e->lat_W;
+    return LNS_OK;
+}
+
+int lns_prepare(lns_engine* e, int B, size_t* workspace_bytes) {
+    if (!e || B <= 0) return LNS_EINVAL;
+    WsLayout L;
+    int rc = ws_layout(e, B, &L);
+    if (rc) return rc;
+    if (workspace_bytes) *workspace_bytes = L.total;
+    return LNS_OK;
+}
+
+static int check_ws(lns_engine* e, const WsLayout& L, void* ws, size_t bytes) {
+    if (!ws || bytes < L.total) { e->err = fmt("workspace too small: need %zu bytes, got %zu", L.total, bytes); return LNS_ENOMEM; }
+    return LNS_OK;
+}
+
+int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
+    if (!e || !x || !z || B <= 0) return LNS_EINVAL;
+    WsLayout L; int rc;
+    if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
+    Plan* p;
+    if ((rc = get_plan(e, PK_ENC, B, 0, 0, &p))) return rc;
+    const lns_config& c = e->cfg;
+    ExtT ext[EX_COUNT];
+    ext[EX_IN] = {x, (long)c.in_channels * c.Ly * c.Lx};
+    ext[EX_OUT] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
+    Runner r(e, static_cast<hipStream_t>(stream));
+    if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
+    return r.finish();
+}
+
+int lns_decode(lns_engine* e, const float* z, int B, float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!e || !z || !y || B <= 0) return LNS_EINVAL;
+    WsLayout L; int rc;
+    if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
+    Plan* p;
+    if ((rc = get_plan(e, PK_DEC, B, 0, 0, &p))) return rc;
+    const lns_config& c = e->cfg;
+    ExtT ext[EX_COUNT];
+    ext[EX_IN] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
+    ext[EX_OUT] = {y, (long)c.in_channels * c.Ly * c.Lx};
+    Runner r(e, static_cast<hipStream_t>(stream));
+    if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
+    return r.finish();
+}
+
+int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, int H, int W, float* z_out, void* ws,
+                  size_t ws_bytes, void* stream) {
+    if (!e || !z_in || !z_out || B <= 0 || H <= 0 || W <= 0) return LNS_EINVAL;
+    if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    Plan* p; int rc;
+    if ((rc = get_plan(e, PK_PROP, B, H, W, &p))) return rc;
+    if (!ws || ws_bytes < p->arena_bytes) { e->err = fmt("workspace too small: need %zu bytes", p->arena_bytes); return LNS_ENOMEM; }
+    ExtT ext[EX_COUNT];
+    const long per = (long)e->cfg.latent_dim * H * W;
+    ext[EX_IN] = {z_in, per};
+    ext[EX_OUT] = {z_out, per};
+    ext[EX_PARAM] = {param, 1};
+    Runner r(e, static_cast<hipStream_t>(stream));
+    if ((rc = r.run(*p, ext, static_cast<char*>(ws)))) return rc;
+    return r.finish();
+}
+
+int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T, int to_x, float* out,
+                float* latents_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!e || !x || !out || B <= 0 || T <= 0) return LNS_EINVAL;
+    if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
+    if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    WsLayout L; int rc;
+    if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
+    Plan *pe, *pp, *pd;
+    if ((rc = get_plan(e, PK_ENC, B, 0, 0, &pe))) return rc;
+    if ((rc = get_plan(e, PK_PROP, B, e->lat_H, e->lat_W, &pp))) return rc;
+    if ((rc = get_plan(e, PK_DEC, B, 0, 0, &pd))) return rc;
+    const lns_config& c = e->cfg;
+    const long zper = (long)e->lat_C * e->lat_H * e->lat_W;
+    const long xper = (long)c.in_channels * c.Ly * c.Lx;
+    char* base = static_cast<char*>(ws);
+    float* zbuf[2] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + L.z_bytes)};
+    char* arena = base + L.arena_off;
+    Runner r(e, static_cast<hipStream_t>(stream));
+    ExtT ext[EX_COUNT];
+    ext[EX_PARAM] = {param, 1};
+    // encode once: x -> z0                                    (train_stage2_ns2d.py:144)
+    ext[EX_IN] = {x, xper};
+    ext[EX_OUT] = {zbuf[0], zper};
+    if ((rc = r.run(*pe, ext, arena))) return rc;
+    ExtT zcur = {zbuf[0], zper};
+    for (int t = 0; t < T; ++t) {   // strictly sequential in t  (train_stage2_ns2d.py:147-156)
+        ExtT znext;
+        if (latents_out) znext = {latents_out + (long)t * zper, (long)T * zper};
+        else if (!to_x) znext = {out + (long)t * zper, (long)T * zper};
+        else znext = {zbuf[(t + 1) & 1], zper};
+        ext[EX_IN] = zcur;
+        ext[EX_OUT] = znext;
+        if ((rc = r.run(*pp, ext, arena))) return rc;
+        if (to_x) {
+            ext[EX_IN] = znext;
+            ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
+            if ((rc = r.run(*pd, ext, arena))) return rc;
+        } else if (latents_out) {
+            HIPCHK(e, hipMemcpy2DAsync(out + (long)t * zper, (size_t)T * zper * 4, znext.ptr, (size_t)T * zper * 4,
+                                       (size_t)zper * 4, B, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+        }
+        zcur = znext;
+    }
+    return r.finish();
+}
+
+// ---- diagnostics -------------------------------------------------------------
+int lns_trace_enable(lns_engine* e, int on) { if (!e) return LNS_EINVAL; e->trace_on = on != 0; e->trace.clear(); return LNS_OK; }
+int lns_trace_count(const lns_engine* e) { return e ? (int)e->trace.size() : LNS_EINVAL; }
+int lns_trace_info(const lns_engine* e, int i, char* name, int cap, int64_t* shape) {
+    if (!e || i < 0 || i >= (int)e->trace.size()) return LNS_EINVAL;
+    const TraceRec& r = e->trace[i];
+    if (name && cap > 0) { strncpy(name, r.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (shape) { shape[0] = r.B; shape[1] = r.C; shape[2] = r.H; shape[3] = r.W; }
+    return LNS_OK;
+}
+int lns_trace_copy(const lns_engine* e, int i, float* host_out) {
+    if (!e || i < 0 || i >= (int)e->trace.size() || !host_out) return LNS_EINVAL;
+    memcpy(host_out, e->trace[i].data.data(), e->trace[i].data.size() * 4);
+    return LNS_OK;
+}
+int lns_timing_enable(lns_engine* e, int on) { if (!e) return LNS_EINVAL; e->timing_on = on != 0; e->timing.clear(); return LNS_OK; }
+int lns_timing_count(const lns_engine* e) { return e ? (int)e->timing.size() : LNS_EINVAL; }
+int lns_timing_info(const lns_engine* e, int i, char* name, int cap, double* ms, int64_t* launches, double* flops,
+                    double* bytes) {
+    if (!e || i < 0 || i >= (int)e->timing.size()) return LNS_EINVAL;
+    const TimeRec& t = e->timing[i];
+    if (name && cap > 0) { strncpy(name, t.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (ms) *ms = t.ms;
+    if (launches) *launches = t.launches;
+    if (flops) *flops = t.flops;
+    if (bytes) *bytes = t.bytes;
+    return LNS_OK;
+}
+
+// ---- kernel-level entry points (tests) ------------------------------------------
+static thread_local std::string g_op_error;
+#define OPCHK(call)                                                                                   \
+    do { hipError_t err__ = (call);                                                                   \
+         if (err__ != hipSuccess) { g_op_error = fmt("%s: %s", #call, hipGetErrorString(err__)); fprintf(stderr, "lns_op: %s\n", g_op_error.c_str()); return LNS_EHIP; } } while (0)
+
+int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv, const float* w_host,
+                  const float* bias_host, int Cout, int ksize, int stride, int dilation, int pad_t, int pad_b, int pad_l,
+                  int pad_r, int mode_y, int mode_x, const float* ss, int act_in, int act_out, const float* residual,
+                  const float* badd, float* y, int tile_variant, void* stream) {
+    if (!x || !w_host || !y || (ksize != 1 && ksize != 3)) return LNS_EINVAL;
+    OPCHK(init_kernels());
+    ConvPack pk;
+    pk.cin = Cin; pk.cout = Cout; pk.k = ksize;
+    pk.kc_log2 = ksize == 3 ? 3 : 5;
+    pk.Cin_pad = (Cin + (1 << pk.kc_log2) - 1) / (1 << pk.kc_log2) * (1 << pk.kc_log2);
+    pk.Cout_pad = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : (Cout + 127) / 128 * 128);
+    if (tile_variant >= 0) {
+        const int TM = conv_variant_info(tile_variant).TM;
+        pk.Cout_pad = (Cout + TM - 1) / TM * TM;
+        if (pk.Cout_pad < 32) pk.Cout_pad = 32;
+    }
+    if (Hv <= 0) Hv = Hin;
+    if (Wv <= 0) Wv = Win;
+    const int pad[4] = {pad_t, pad_b, pad_l, pad_r};
+    ConvGeom g;
+    if (!conv_geometry(g, B, Cout, Hv, Wv, ksize, stride, dilation, pad, pk.kc_log2, pk.Cout_pad, tile_variant)) return LNS_EINVAL;
+    const ConvVariantInfo vi = conv_variant_info(g.variant);
+    const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
+    std::vector<int> rm, cm;
+    const float sch = (Hv == 2 * Hin) ? 0.5f : 0.0f, scw = (Wv == 2 * Win) ? 0.5f : 0.0f;
+    build_axis_map(rm, (g.tiles_y - 1) * BH * stride + g.PH, Hin, Hv, sch, pad_t, pad_b, mode_y);
+    build_axis_map(cm, (g.tiles_x - 1) * BW * stride + g.PW, Win, Wv, scw, pad_l, pad_r, mode_x);
+    const size_t wcount = (size_t)ksize * ksize * pk.Cin_pad * pk.Cout_pad;
+    std::vector<float> hw(wcount + pk.Cout_pad, 0.0f);
+    pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
+    if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
+    float* dw = nullptr; int* dmaps = nullptr;
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&dw), hw.size() * 4));
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&dmaps), (rm.size() + cm.size()) * 4));
+    OPCHK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(dmaps, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(dmaps + rm.size(), cm.data(), cm.size() * 4, hipMemcpyHostToDevice));
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.x_bs = (long)Cin * Hin * Win; a.Cin = Cin; a.Hin = Hin; a.Win = Win;
+    a.w = dw; a.bias = bias_host ? dw + wcount : nullptr; a.ss = ss; a.act_in = act_in; a.act_out = act_out;
+    a.rowmap = dmaps; a.colmap = dmaps + rm.size();
+    a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
+    a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
+    a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
+    a.kc_log2 = pk.kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
+    a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OPCHK(launch_conv(g.variant, a, s));
+    OPCHK(hipStreamSynchronize(s));
+    hipFree(dw); hipFree(dmaps);
+    return LNS_OK;
+}
+
+int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, float eps, const float* gamma_host,
+                           const float* beta_host, const float* premul, float* ss, void* stream) {
+    if (!x || !ss || C % groups) return LNS_EINVAL;
+    float* dgb = nullptr;
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&dgb), (size_t)2 * C * 4));
+    if (gamma_host) OPCHK(hipMemcpy(dgb, gamma_host, (size_t)C * 4, hipMemcpyHostToDevice));
+    if (beta_host) OPCHK(hipMemcpy(dgb + C, beta_host, (size_t)C * 4, hipMemcpyHostToDevice));
+    GnStatsArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.x_bs = (long)C * HW; a.C = C; a.HW = HW; a.groups = groups; a.eps = eps;
+    a.gamma = gamma_host ? dgb : nullptr; a.beta = beta_host ? dgb + C : nullptr; a.premul = premul; a.ss = ss; a.B = B;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OPCHK(launch_gn_stats(a, s));
+    OPCHK(hipStreamSynchronize(s));
+    hipFree(dgb);
+    return LNS_OK;
+}
+
+int lns_op_attention(const float* qkv, int B, int heads, int dim_head, int n, float scale, float* o, void* stream) {
+    if (!qkv || !o) return LNS_EINVAL;
+    AttnArgs a = {qkv, B, heads, dim_head, n, scale, o};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OPCHK(launch_attention(a, s));
+    OPCHK(hipStreamSynchronize(s));
+    return LNS_OK;
+}
+
+int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, int heads, int C, int H, int W, float eps,
+                       int apply_instance_norm, float* out, void* stream) {
+    if (!u || !kx || !ky || !out) return LNS_EINVAL;
+    OPCHK(init_kernels());
+    FaSandwichArgs a = {u, kx, ky, B, heads, C, H, W, eps, apply_instance_norm, out};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OPCHK(launch_fa_sandwich(a, s));
+    OPCHK(hipStreamSynchronize(s));
+    return LNS_OK;
+}
+
+}  // extern "C"

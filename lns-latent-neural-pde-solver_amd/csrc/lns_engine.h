@@ -1,0 +1,132 @@
+// Internal structures of the LNS rollout engine (host side, C++).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lns.h"
+#include "lns_kernels.h"
+
+namespace lns {
+
+// ---- parameter table (= reference state_dict) -------------------------------
+struct Param {
+    std::string key;
+    std::vector<int64_t> shape;
+    std::vector<float> host;
+    bool is_buffer = false;
+    bool is_set = false;
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+// conv / linear weight in kernel-native layout [taps][Cin_pad][Cout_pad]
+struct ConvPack {
+    std::vector<std::string> wkeys;   // concatenated along Cout
+    std::vector<std::string> bkeys;   // "" entry => zero bias for that slice
+    std::vector<int> couts;
+    int cin = 0, cout = 0, k = 1;
+    bool has_bias = false;
+    int Cin_pad = 0, Cout_pad = 0, kc_log2 = 3;
+    size_t w_off = 0, b_off = 0;      // float offsets in the device weight blob
+};
+
+enum VecXform { VX_NONE = 0, VX_TRANSPOSE2D = 1, VX_PE_T = 2 };
+struct VecPack { std::string key; int xform = VX_NONE; size_t off = 0; size_t count = 0; };
+
+// ---- layer IR (mirrors the reference nn.Sequential entries) ------------------
+enum LType { LT_CONV, LT_SWISH, LT_GN, LT_RES, LT_UP2, LT_RESIZE, LT_SA, LT_FA, LT_FOURIER, LT_PROPBLOCK, LT_CONDBLOCK };
+
+struct Layer {
+    LType type = LT_CONV;
+    std::string name;
+    // conv
+    int pack = -1, k = 1, stride = 1, dil = 1;
+    int pad[4] = {0, 0, 0, 0};   // top, bottom, left, right
+    int mode_y = 0, mode_x = 0;
+    // group norm
+    int groups = 0; float eps = 0; int vg = -1, vb = -1; int C = 0;
+    // residual block
+    int g1 = -1, b1 = -1, g2 = -1, b2 = -1, conv1 = -1, conv2 = -1, chup = -1, cin = 0, cout = 0;
+    // resize
+    int outH = 0, outW = 0;
+    // self attention
+    int heads = 0, dim_head = 0, ln_g = -1, ln_b = -1, pe = -1, pe_len = 0, qkv = -1, proj = -1;
+    // factorized attention
+    int fa_g = -1, fa_b = -1, inproj = -1, toin = -1, qkx = -1, qky = -1, out1 = -1, out3 = -1;
+    int rx[6] = {-1, -1, -1, -1, -1, -1}, ry[6] = {-1, -1, -1, -1, -1, -1};
+    std::string invf_x, invf_y;
+    int fa_lat = 0, fa_dk = 0;
+    // propagator block
+    int p_g1 = -1, p_b1 = -1, p_c1 = -1, p_c3 = -1, p_c5 = -1, p_g2 = -1, p_b2 = -1, p_f1 = -1, p_f3 = -1;
+    // conditional block extras
+    int c_g = -1, c_b = -1, c_conv = -1, blk_index = 0;
+    // fourier block
+    int f_conv = -1, f_w1 = -1, f_w2 = -1, m1 = 0, m2 = 0, f_cond_w = -1, f_cond_b = -1, f_lin = -1;
+};
+
+// ---- launch plan ---------------------------------------------------------------
+enum Space { SP_NULL = 0, SP_WS = 1, SP_WT = 2, SP_CT = 3, SP_EXT0 = 4 };   // ext slots: 4..11
+enum ExtSlot { EX_IN = 0, EX_OUT = 1, EX_PARAM = 2, EX_COUNT = 3 };
+
+enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FALRK, OP_FASAND, OP_COND, OP_SPECTRAL,
+              OP_FCOMBINE, OP_TRACE };
+
+struct Op {
+    OpType type;
+    std::string name;
+    int cls = 0;          // timing class
+    double flops = 0, bytes = 0;
+    int variant = 0;
+    ConvArgs conv;
+    GnStatsArgs gn;
+    LnPeArgs ln;
+    AttnArgs at;
+    FaPoolArgs fp;
+    FaReducerArgs fr;
+    FaLrkArgs fl;
+    FaSandwichArgs fs;
+    CondArgs cd;
+    SpectralArgs sp;
+    FourierCombineArgs fc;
+    // trace
+    uint64_t t_ptr = 0; long t_bs = 0; int tC = 0, tH = 0, tW = 0;
+};
+
+struct Plan {
+    std::vector<Op> ops;
+    std::vector<int> consts_i;        // host copy of int constants
+    std::vector<float> consts_f;      // host copy of float constants
+    void* d_consts = nullptr;         // device: ints then floats
+    size_t arena_bytes = 0;
+    int B = 0, H = 0, W = 0;
+};
+
+struct ExtT { const void* ptr = nullptr; long bs = 0; };
+
+struct TraceRec { std::string name; int B, C, H, W; std::vector<float> data; };
+struct TimeRec { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
+
+}  // namespace lns
+
+struct lns_engine {
+    lns_config cfg;
+    std::string err;
+    std::vector<lns::Param> params;
+    std::map<std::string, int> pindex;
+    std::vector<lns::ConvPack> packs;
+    std::vector<lns::VecPack> vecs;
+    std::vector<lns::Layer> enc, dec, prop;
+    int lat_C = 0, lat_H = 0, lat_W = 0;
+    // device weights
+    float* d_weights = nullptr;
+    size_t weights_floats = 0;
+    bool finalized = false;
+    int device = -1;
+    // plans keyed by batch (encode/decode) or (B,H,W) for the propagator
+    std::map<long, lns::Plan> enc_plans, dec_plans, prop_plans;
+    // diagnostics
+    bool trace_on = false;
+    std::vector<lns::TraceRec> trace;
+    bool timing_on = false;
+    std::vector<lns::TimeRec> timing;
+};

@@ -1,0 +1,138 @@
+// Kernel argument blocks and host-side launchers of the gfx950 HIP kernels.
+// All tensors fp32 NCHW.  See DESIGN.md for the roofline of each kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lns {
+
+enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_GELU = 2 };
+
+// ---------------------------------------------------------------------------
+// fused implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32)
+//   y = act_out(conv(act_in(x*scale+shift)) + bias + badd) + residual
+// ---------------------------------------------------------------------------
+struct ConvArgs {
+    const float* x;        // [B, Cin, Hin, Win], batch stride x_bs floats
+    long x_bs;
+    int Cin, Hin, Win;
+    const float* w;        // packed [taps][Cin_pad][Cout_pad]
+    const float* bias;     // [Cout] or null
+    const float* ss;       // [B][Cin][2] (scale, shift) or null
+    int act_in, act_out;
+    const int* rowmap;     // padded/virtual row  -> source row or -1
+    const int* colmap;     // padded/virtual col  -> source col or -1
+    float* y;              // [B, Cout, Hout, Wout], batch stride y_bs
+    long y_bs;
+    int Cout, Hout, Wout;
+    const float* res;      // residual, same shape as y (batch stride res_bs) or null
+    long res_bs;
+    const float* badd;     // [B][Cout] broadcast add or null
+    int ks, stride, dil;
+    int Cin_pad, Cout_pad;
+    int kc_log2;           // channels per LDS stage = 1<<kc_log2
+    int tiles_x, tiles_y, cout_tiles;
+    int bw_log2;           // pixel tile width = 1<<bw_log2, height = TN>>bw_log2
+    int PH, PW;            // staged patch extent
+    int B;
+};
+
+// tile variants: (TM couts x TN pixels) per 256-thread block
+enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4, CV_S32 = 5, CV_COUNT = 6 };
+struct ConvVariantInfo { int TM, TN; };
+ConvVariantInfo conv_variant_info(int v);
+size_t conv_lds_bytes(int variant, const ConvArgs& a);
+hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// GroupNorm statistics -> per-(b,c) scale/shift (fused into the consumer conv)
+// ---------------------------------------------------------------------------
+struct GnStatsArgs {
+    const float* x; long x_bs; int C, HW, groups; float eps;
+    const float* gamma; const float* beta;   // device, [C] (null => 1 / 0)
+    const float* premul;                     // [B][C] or null: stats of x*premul
+    float* ss;                               // [B][C][2]
+    int B;
+};
+hipError_t launch_gn_stats(const GnStatsArgs& a, hipStream_t s);
+
+// LayerNorm over channels of a channel-major token tensor + positional embedding
+struct LnPeArgs {
+    const float* x; long x_bs; int C, n; float eps;
+    const float* gamma; const float* beta;   // [C]
+    const float* pe_t;                       // [C][pe_stride] transposed positional table or null
+    int pe_stride;
+    float* h;                                // [B][C][n]
+    int B;
+};
+hipError_t launch_ln_pe(const LnPeArgs& a, hipStream_t s);
+
+// softmax attention, channel-major qkv [B, 3*heads*D, n] -> o [B, heads*D, n]
+struct AttnArgs { const float* qkv; int B, heads, D, n; float scale; float* o; };
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// FABlock2D pieces ----------------------------------------------------------
+struct FaPoolArgs { const float* v; int B, C, H, W; float* mx; float* my; };   // mx [B,H,C], my [B,W,C]
+hipError_t launch_fa_pool(const FaPoolArgs& a, hipStream_t s);
+
+struct FaReducerArgs {                 // PoolingReducer on pooled rows [rows, C]
+    const float* m; long rows; int n;  // rows = B*n ; output u [B, Out, n] channel-major
+    int C, Hid, Out;
+    const float* win_t;                // [C][C]   (in-major)
+    const float* ln_g; const float* ln_b;
+    const float* w1_t;                 // [C][Hid]
+    const float* w2_t;                 // [Hid][Out]
+    const float* b2;                   // [Out]
+    float* u;
+};
+hipError_t launch_fa_reducer(const FaReducerArgs& a, hipStream_t s);
+
+struct FaLrkArgs {                     // rotary + q k^T
+    const float* qk;                   // [B, 2*heads*DK, n]
+    int B, heads, DK, n;
+    const float* cs;                   // [n][DK/2][2] (cos, sin)
+    float* kmat;                       // [B, heads, n, n]
+};
+hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s);
+
+struct FaSandwichArgs {
+    const float* u; const float* kx; const float* ky;
+    int B, heads, C, H, W; float eps; int instnorm; float* out;
+};
+hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s);
+size_t fa_sandwich_lds_bytes(int H, int W);
+
+// conditional propagator: per-sample embedding MLPs (step-invariant) ---------
+struct CondArgs {
+    const float* param; int B, E /*cond_emb_dim*/, D /*prop_n_embd*/, nblk;
+    const float* p0_wt; const float* p0_b;   // cond_emb_proj.0 : [E][E] in-major, [E]
+    const float* p2_wt; const float* p2_b;   // cond_emb_proj.2
+    // per block (arrays of nblk device pointers are avoided: weights are packed contiguously)
+    const float* blk;      // per block: ce_wt [E][D], ce_b [D], gn_g [D], gn_b [D], c1_wt [D][D], c1_b [D], c3_wt [D][D], c3_b [D]
+    long blk_stride;
+    float* emb;            // [nblk][B][D]   cond_emb(cond)            (added after conv1)
+    float* mul;            // [nblk][B][D]   1 + cond_conv2(emb)       (pre-multiplier of ffn input)
+};
+hipError_t launch_cond(const CondArgs& a, hipStream_t s);
+
+// Fourier blocks (opt-in): truncated DFT as dense contractions ---------------
+struct SpectralArgs {
+    const float* x; int B, Cin, Cout, H, W, m1, m2;
+    const float* w1; const float* w2;     // [Cin][Cout][m1][m2][2]
+    const float* emb;                     // [B][m1][m2][2][2] complex cond scaling or null
+    const float* tw_h;                    // [H][H][2] cos/sin(2*pi*k*y/H)
+    const float* tw_w;                    // [W][W][2]
+    float* xf;                            // workspace [B][Cin][2*m1][m2][2]
+    float* of;                            // workspace [B][Cout][2*m1][m2][2]
+    float* tmp;                           // workspace [B][max(Cin,Cout)][H][m2][2]
+    float* y;                             // [B][Cout][H][W]   (spectral conv output)
+};
+hipError_t launch_spectral(const SpectralArgs& a, hipStream_t s);
+
+// y = skip + gelu(a + b + e[b,c])
+struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; float* y; int B, C, HW; };
+hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s);
+
+hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
+
+}  // namespace lns

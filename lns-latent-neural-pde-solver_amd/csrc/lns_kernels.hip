@@ -1,0 +1,795 @@
+// gfx950 (MI355X / CDNA4) kernels of the LNS rollout hot path.
+//
+// Numerics: everything is fp32 end to end.  The dense contractions run on the
+// exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (one rounding per
+// product, k-ordered fmaf chain), because the 1e-4 rel-L2 parity budget over a
+// 64-step autoregressive rollout excludes bf16/fp16.
+//
+// 64-lane wavefront conventions used throughout:
+//   l31 = lane & 31, kh = lane >> 5
+//   A operand (32 x 2):  lane holds A[row l31][k = kh]
+//   B operand (2 x 32):  lane holds B[k = kh][col l31]
+//   C/D (32 x 32, 16 regs): reg r of lane holds D[row (r&3) + 8*(r>>2) + 4*kh][col l31]
+#include "lns_kernels.h"
+
+namespace lns {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == ACT_SWISH) return v / (1.0f + expf(-v));
+    if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+__device__ __forceinline__ int drow(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); red must hold >= 4 floats
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ===========================================================================
+// Convolution: implicit GEMM, D[cout][pixel] = W[cout][k] * im2col(X)[k][pixel]
+//   - weights are the MFMA A operand (rows = couts), activations the B operand
+//     (cols = pixels): output rows land in registers, output pixels on lanes, so
+//     every store instruction writes 128-byte contiguous NCHW row segments;
+//   - per K stage (KC input channels): the haloed input patch is staged in LDS
+//     with the producer's GroupNorm scale/shift + activation applied on the fly
+//     (padding / circular wrap / nearest-upsample resolved through row/col
+//     index maps, never materialised), next to the [tap][k][cout] weight slab;
+//   - K order inside a stage: tap-major, channel pairs (k = 2*kk + kh).
+// ===========================================================================
+struct __attribute__((aligned(16))) RowEnt { int off; float s; float t; int pad; };
+
+template <int MT, int NT, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int NTHR = 64 * WGM * WGN;
+    constexpr int TM = WGM * MT * 32;
+    constexpr int TN = WGN * NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int KC = 1 << a.kc_log2;
+    const int PH = a.PH, PW = a.PW;
+    const int PLANE = PH * PW;
+    const int taps = a.ks * a.ks;
+    const int xs_floats = (KC * PLANE + 3) & ~3;
+    float* Xs = reinterpret_cast<float*>(smem);
+    float* Ws = Xs + xs_floats;
+    RowEnt* rowtab = reinterpret_cast<RowEnt*>(Ws + taps * KC * TM);
+    int* coltab = reinterpret_cast<int*>(rowtab + KC * PH);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int b = blockIdx.y;
+    int bid = blockIdx.x;
+    const int ct = bid % a.cout_tiles;
+    bid /= a.cout_tiles;
+    const int tx = bid % a.tiles_x;
+    const int ty = bid / a.tiles_x;
+    const int BW = 1 << a.bw_log2;
+    const int BH = TN >> a.bw_log2;
+    const int HWin = a.Hin * a.Win;
+    const float* xb = a.x + (long)b * a.x_bs;
+
+    for (int px = tid; px < PW; px += NTHR) coltab[px] = a.colmap[tx * BW * a.stride + px];
+
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = (wn * NT + nt) * 32 + l31;
+        boff[nt] = ((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    // flat staging index -> (row, col) of the patch, advanced incrementally
+    const int r_start = tid / PW, c_start = tid - r_start * PW;
+    const int r_step = NTHR / PW, c_step = NTHR - r_step * PW;
+    const int rowbase = ty * BH * a.stride;
+
+    for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
+        __syncthreads();   // previous stage fully consumed (also orders coltab on the first pass)
+        for (int r = tid; r < KC * PH; r += NTHR) {
+            const int cl = r / PH;
+            const int py = r - cl * PH;
+            const int c = c0 + cl;
+            const int sy = a.rowmap[rowbase + py];
+            RowEnt e;
+            e.off = -1; e.s = 1.0f; e.t = 0.0f; e.pad = 0;
+            if (c < a.Cin && sy >= 0) {
+                e.off = cl * HWin + sy * a.Win;
+                if (a.ss) {
+                    e.s = a.ss[((long)b * a.Cin + c) * 2];
+                    e.t = a.ss[((long)b * a.Cin + c) * 2 + 1];
+                }
+            }
+            rowtab[r] = e;
+        }
+        // weight slab: rows (tap, k) of TM contiguous couts
+        {
+            constexpr int V4 = TM / 4;
+            const int nrow = taps * KC;
+            for (int i = tid; i < nrow * V4; i += NTHR) {
+                const int row = i / V4, c4 = i - row * V4;
+                const int tap = row >> a.kc_log2, k = row & (KC - 1);
+                const float4 v = *reinterpret_cast<const float4*>(
+                    a.w + ((long)(tap * a.Cin_pad + c0 + k) * a.Cout_pad + ct * TM + c4 * 4));
+                *reinterpret_cast<float4*>(Ws + row * TM + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        {
+            const float* xc = xb + (long)c0 * HWin;
+            int r = r_start, cx = c_start;
+            const int total = KC * PLANE;
+            for (int idx = tid; idx < total; idx += NTHR) {
+                const RowEnt e = rowtab[r];
+                const int sx = coltab[cx];
+                float v = 0.0f;
+                if (e.off >= 0 && sx >= 0) {
+                    v = xc[e.off + sx] * e.s + e.t;
+                    v = act_apply(v, a.act_in);
+                }
+                Xs[idx] = v;
+                r += r_step;
+                cx += c_step;
+                if (cx >= PW) { cx -= PW; ++r; }
+            }
+        }
+        __syncthreads();
+
+        const float* wbase = Ws + wm * (MT * 32) + l31 + kh * TM;
+        const float* xbase = Xs + kh * PLANE;
+        for (int ky = 0; ky < a.ks; ++ky)
+            for (int kx = 0; kx < a.ks; ++kx) {
+                const float* wsp = wbase + (ky * a.ks + kx) * KC * TM;
+                const float* xsp = xbase + (ky * a.dil) * PW + kx * a.dil;
+#pragma unroll 4
+                for (int kk = 0; kk < KC / 2; ++kk) {
+                    float av[MT], bv[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = wsp[(2 * kk) * TM + mt * 32];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = xsp[(2 * kk) * PLANE + boff[nt]];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+    }
+
+    // epilogue
+    const int HWo = a.Hout * a.Wout;
+    float* yb = a.y + (long)b * a.y_bs;
+    const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = (wn * NT + nt) * 32 + l31;
+        const int oy = ty * BH + (p >> a.bw_log2);
+        const int ox = tx * BW + (p & (BW - 1));
+        const bool pv = (oy < a.Hout) && (ox < a.Wout);
+        const long pix = (long)oy * a.Wout + ox;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * TM + (wm * MT + mt) * 32 + drow(r, kh);
+                if (pv && co < a.Cout) {
+                    float v = acc[mt][nt][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.badd) v += a.badd[(long)b * a.Cout + co];
+                    v = act_apply(v, a.act_out);
+                    const long o = (long)co * HWo + pix;
+                    if (rb) v += rb[o];
+                    yb[o] = v;
+                }
+            }
+        }
+    }
+}
+
+static const ConvVariantInfo kConvInfo[CV_COUNT] = {
+    {128, 256}, {64, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 128}};
+
+ConvVariantInfo conv_variant_info(int v) { return kConvInfo[v]; }
+
+size_t conv_lds_bytes(int variant, const ConvArgs& a) {
+    const int KC = 1 << a.kc_log2;
+    const int TM = kConvInfo[variant].TM;
+    size_t xs = ((size_t)KC * a.PH * a.PW + 3) & ~(size_t)3;
+    size_t ws = (size_t)a.ks * a.ks * KC * TM;
+    return (xs + ws) * 4 + (size_t)KC * a.PH * sizeof(RowEnt) + (size_t)a.PW * 4 + 16;
+}
+
+template <int MT, int NT, int WGM, int WGN>
+static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
+    dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
+    const size_t lds = conv_lds_bytes(variant, a);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    switch (variant) {
+        case CV_L128: return launch_conv_t<2, 4, 2, 2>(a, lds, s);
+        case CV_L64: return launch_conv_t<2, 2, 1, 4>(a, lds, s);
+        case CV_M128: return launch_conv_t<2, 2, 2, 2>(a, lds, s);
+        case CV_M64: return launch_conv_t<2, 1, 1, 4>(a, lds, s);
+        case CV_S64: return launch_conv_t<1, 1, 2, 2>(a, lds, s);
+        case CV_S32: return launch_conv_t<1, 1, 1, 4>(a, lds, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// GroupNorm statistics: one block per (group, sample); two-pass (mean, then
+// centred second moment) over a contiguous (C/groups)*HW slab.  HBM-bound.
+// ===========================================================================
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsArgs a) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cg = a.C / a.groups;
+    const long n = (long)cg * a.HW;
+    const float* xs = a.x + (long)b * a.x_bs + (long)g * cg * a.HW;
+    const float* pm = a.premul ? a.premul + (long)b * a.C + g * cg : nullptr;
+    float s = 0.0f;
+    if (!pm && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15) == 0)) {
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        for (long i = threadIdx.x; i < (n >> 2); i += 256) {
+            const float4 v = x4[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) {
+            float v = xs[i];
+            if (pm) v *= pm[i / a.HW];
+            s += v;
+        }
+    }
+    const float mean = block_sum_256(s, red) / (float)n;
+    float q = 0.0f;
+    if (!pm && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15) == 0)) {
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        for (long i = threadIdx.x; i < (n >> 2); i += 256) {
+            const float4 v = x4[i];
+            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) {
+            float v = xs[i];
+            if (pm) v *= pm[i / a.HW];
+            const float d = v - mean;
+            q += d * d;
+        }
+    }
+    const float var = block_sum_256(q, red) / (float)n;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    for (int c = threadIdx.x; c < cg; c += 256) {
+        const int ch = g * cg + c;
+        const float ga = a.gamma ? a.gamma[ch] : 1.0f;
+        const float be = a.beta ? a.beta[ch] : 0.0f;
+        const float p = pm ? pm[c] : 1.0f;
+        a.ss[((long)b * a.C + ch) * 2] = rstd * ga * p;
+        a.ss[((long)b * a.C + ch) * 2 + 1] = be - mean * rstd * ga;
+    }
+}
+
+hipError_t launch_gn_stats(const GnStatsArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// SABlock pre-norm: h[b,c,i] = LN_c(x[b,:,i]) * g[c] + b[c] + pe[i,c]
+// one thread per token, channel loops are coalesced across the wave.
+// ===========================================================================
+__global__ __launch_bounds__(256) void ln_pe_kernel(LnPeArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= a.n) return;
+    const float* xs = a.x + (long)b * a.x_bs + i;
+    float s = 0.0f;
+    for (int c = 0; c < a.C; ++c) s += xs[(long)c * a.n];
+    const float mean = s / (float)a.C;
+    float q = 0.0f;
+    for (int c = 0; c < a.C; ++c) {
+        const float d = xs[(long)c * a.n] - mean;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+    float* hs = a.h + (long)b * a.C * a.n + i;
+    for (int c = 0; c < a.C; ++c) {
+        float v = (xs[(long)c * a.n] - mean) * rstd * a.gamma[c] + a.beta[c];
+        if (a.pe_t) v += a.pe_t[(long)c * a.pe_stride + i];
+        hs[(long)c * a.n] = v;
+    }
+}
+
+hipError_t launch_ln_pe(const LnPeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(ln_pe_kernel, dim3((a.n + 255) / 256, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// Softmax attention (SABlock core), flash-style online softmax on fp32 MFMA.
+// Block = 4 waves = 128 queries of one (sample, head); K/V tiles of 32 keys go
+// through LDS.  S^T = K^T Q puts the query on the lane, so the row softmax is
+// lane-local (+ one cross-half shuffle) and the S^T accumulator is directly the
+// B operand of O^T += V P^T (k-step r <-> accumulator register r; the A operand
+// V is fetched in the matching permuted key order).
+// ===========================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    __shared__ float Ks[D * 32];
+    __shared__ float Vs[D * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int n = a.n;
+    const long inner = (long)a.heads * D;
+    const float* qb = a.qkv + ((long)b * 3 * inner + (long)h * D) * n;
+    const float* kb = qb + inner * n;
+    const float* vb = kb + inner * n;
+    const int query = (blockIdx.x * 4 + wave) * 32 + l31;
+    const bool qvalid = query < n;
+
+    float qreg[D / 2];
+#pragma unroll
+    for (int kk = 0; kk < D / 2; ++kk) qreg[kk] = qvalid ? qb[(long)(2 * kk + kh) * n + query] : 0.0f;
+
+    float m = -INFINITY, l = 0.0f;
+    f32x16 oacc[D / 32];
+#pragma unroll
+    for (int mt = 0; mt < D / 32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.0f;
+
+    const int ntile = (n + 31) / 32;
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int key0 = kt * 32;
+        __syncthreads();
+        for (int i = tid; i < D * 32; i += 256) {
+            const int d = i >> 5, j = i & 31;
+            const int key = key0 + j;
+            const bool kv = key < n;
+            Ks[d * 32 + j] = kv ? kb[(long)d * n + key] : 0.0f;
+            Vs[d * 33 + j] = kv ? vb[(long)d * n + key] : 0.0f;
+        }
+        __syncthreads();
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < D / 2; ++kk)
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * kk + kh) * 32 + l31], qreg[kk], sacc, 0, 0, 0);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + drow(r, kh);
+            float sv = sacc[r] * a.scale;
+            if (key >= n) sv = -INFINITY;
+            sacc[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = expf(m - mnew);
+        float lt = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(sacc[r] - mnew);
+            sacc[r] = p;
+            lt += p;
+        }
+        lt += __shfl_xor(lt, 32);
+        l = l * alpha + lt;
+        m = mnew;
+#pragma unroll
+        for (int mt = 0; mt < D / 32; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(mt * 32 + l31) * 33 + drow(r, kh)], sacc[r],
+                                                                  oacc[mt], 0, 0, 0);
+        }
+    }
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        float* ob = a.o + ((long)b * inner + (long)h * D) * n + query;
+#pragma unroll
+        for (int mt = 0; mt < D / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[(long)(mt * 32 + drow(r, kh)) * n] = oacc[mt][r] * inv;
+    }
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    dim3 grid((a.n + 127) / 128, a.heads, a.B);
+    if (a.D == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, a);
+    else if (a.D == 32) hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// FABlock2D: axis pooling of v [B,C,H,W] -> mx [B,H,C] (mean over W), my [B,W,C]
+// ===========================================================================
+__global__ __launch_bounds__(256) void fa_pool_kernel(FaPoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* P = reinterpret_cast<float*>(smem);
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int H = a.H, W = a.W, WP = W + 1;
+    const float* vs = a.v + ((long)b * a.C + c) * H * W;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = i / W, x = i - y * W;
+        P[y * WP + x] = vs[i];
+    }
+    __syncthreads();
+    for (int y = threadIdx.x; y < H; y += 256) {
+        float s = 0.0f;
+        for (int x = 0; x < W; ++x) s += P[y * WP + x];
+        a.mx[((long)b * H + y) * a.C + c] = s / (float)W;
+    }
+    for (int x = threadIdx.x; x < W; x += 256) {
+        float s = 0.0f;
+        for (int y = 0; y < H; ++y) s += P[y * WP + x];
+        a.my[((long)b * W + x) * a.C + c] = s / (float)H;
+    }
+}
+
+hipError_t launch_fa_pool(const FaPoolArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)a.H * (a.W + 1) * 4;
+    hipLaunchKernelGGL(fa_pool_kernel, dim3(a.C, a.B), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// FABlock2D PoolingReducer on pooled rows: to_in -> LayerNorm -> Linear ->
+// GELU -> Linear(+bias).  8 rows per block so every weight is read once per 8
+// rows; weights are stored in-major so lanes read consecutive outputs.
+// ===========================================================================
+#define FAR_ROWS 8
+__global__ __launch_bounds__(128) void fa_reducer_kernel(FaReducerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = a.C, Hid = a.Hid, Out = a.Out;
+    float* vin = reinterpret_cast<float*>(smem);      // [R][C]
+    float* t = vin + FAR_ROWS * C;                    // [R][C]
+    float* hb = t + FAR_ROWS * C;                     // [R][Hid]
+    float* stat = hb + FAR_ROWS * Hid;                // [R][2]
+    const long row0 = (long)blockIdx.x * FAR_ROWS;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < FAR_ROWS * C; i += 128) {
+        const long row = row0 + i / C;
+        vin[i] = row < a.rows ? a.m[row * C + (i % C)] : 0.0f;
+    }
+    __syncthreads();
+    for (int o = tid; o < C; o += 128) {
+        float acc[FAR_ROWS];
+#pragma unroll
+        for (int r = 0; r < FAR_ROWS; ++r) acc[r] = 0.0f;
+        for (int i = 0; i < C; ++i) {
+            const float w = a.win_t[i * C + o];
+#pragma unroll
+            for (int r = 0; r < FAR_ROWS; ++r) acc[r] += w * vin[r * C + i];
+        }
+#pragma unroll
+        for (int r = 0; r < FAR_ROWS; ++r) t[r * C + o] = acc[r];
+    }
+    __syncthreads();
+    if (tid < FAR_ROWS) {
+        float s = 0.0f;
+        for (int i = 0; i < C; ++i) s += t[tid * C + i];
+        const float mean = s / (float)C;
+        float q = 0.0f;
+        for (int i = 0; i < C; ++i) {
+            const float d = t[tid * C + i] - mean;
+            q += d * d;
+        }
+        stat[tid * 2] = mean;
+        stat[tid * 2 + 1] = 1.0f / sqrtf(q / (float)C + 1e-5f);
+    }
+    __syncthreads();
+    for (int i = tid; i < FAR_ROWS * C; i += 128) {
+        const int r = i / C, c = i % C;
+        t[i] = (t[i] - stat[r * 2]) * stat[r * 2 + 1] * a.ln_g[c] + a.ln_b[c];
+    }
+    __syncthreads();
+    for (int j = tid; j < Hid; j += 128) {
+        float acc[FAR_ROWS];
+#pragma unroll
+        for (int r = 0; r < FAR_ROWS; ++r) acc[r] = 0.0f;
+        for (int i = 0; i < C; ++i) {
+            const float w = a.w1_t[i * Hid + j];
+#pragma unroll
+            for (int r = 0; r < FAR_ROWS; ++r) acc[r] += w * t[r * C + i];
+        }
+#pragma unroll
+        for (int r = 0; r < FAR_ROWS; ++r) hb[r * Hid + j] = act_apply(acc[r], ACT_GELU);
+    }
+    __syncthreads();
+    for (int o = tid; o < Out; o += 128) {
+        float acc[FAR_ROWS];
+#pragma unroll
+        for (int r = 0; r < FAR_ROWS; ++r) acc[r] = 0.0f;
+        for (int j = 0; j < Hid; ++j) {
+            const float w = a.w2_t[j * Out + o];
+#pragma unroll
+            for (int r = 0; r < FAR_ROWS; ++r) acc[r] += w * hb[r * Hid + j];
+        }
+        const float bo = a.b2[o];
+#pragma unroll
+        for (int r = 0; r < FAR_ROWS; ++r) {
+            const long row = row0 + r;
+            if (row < a.rows) {
+                const long bi = row / a.n, i = row - bi * a.n;
+                a.u[(bi * Out + o) * a.n + i] = acc[r] + bo;
+            }
+        }
+    }
+}
+
+hipError_t launch_fa_reducer(const FaReducerArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)FAR_ROWS * (2 * a.C + a.Hid + 2) * 4;
+    const unsigned nb = (unsigned)((a.rows + FAR_ROWS - 1) / FAR_ROWS);
+    hipLaunchKernelGGL(fa_reducer_kernel, dim3(nb), dim3(128), lds, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// FABlock2D LowRankKernel: rotary embedding of q,k then K = q k^T per (b,head)
+// (no softmax, no scaling).  q',k' staged in LDS as [d][n_pad]; MFMA tiles.
+// ===========================================================================
+__global__ __launch_bounds__(256) void fa_lrk_kernel(FaLrkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = a.n, DK = a.DK, half = DK >> 1;
+    const int nt = (n + 31) / 32, npad = nt * 32;
+    float* qs = reinterpret_cast<float*>(smem);   // [DK][npad]
+    float* ks = qs + (size_t)DK * npad;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const float* qb = a.qk + ((long)b * 2 * a.heads * DK + (long)h * DK) * n;
+    const float* kb = qb + (long)a.heads * DK * n;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < DK * npad; i += 256) {
+        const int d = i / npad, j = i - d * npad;
+        float qv = 0.0f, kv = 0.0f;
+        if (j < n) {
+            const int dm = d < half ? d : d - half;
+            const float cs = a.cs[((long)j * half + dm) * 2];
+            const float sn = a.cs[((long)j * half + dm) * 2 + 1];
+            const int dp = d < half ? d + half : d - half;
+            const float sg = d < half ? -1.0f : 1.0f;
+            qv = qb[(long)d * n + j] * cs + sg * qb[(long)dp * n + j] * sn;
+            kv = kb[(long)d * n + j] * cs + sg * kb[(long)dp * n + j] * sn;
+        }
+        qs[i] = qv;
+        ks[i] = kv;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    float* ob = a.kmat + ((long)b * a.heads + h) * n * n;
+    for (int tile = wave; tile < nt * nt; tile += 4) {
+        const int it = tile / nt, jt = tile - it * nt;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float* qp = qs + it * 32 + l31 + kh * npad;
+        const float* kp = ks + jt * 32 + l31 + kh * npad;
+#pragma unroll 8
+        for (int kk = 0; kk < half; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * kk * npad], kp[2 * kk * npad], acc, 0, 0, 0);
+        const int j = jt * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = it * 32 + drow(r, kh);
+            if (i < n && j < n) ob[(long)i * n + j] = acc[r];
+        }
+    }
+}
+
+hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s) {
+    const int npad = ((a.n + 31) / 32) * 32;
+    const size_t lds = (size_t)2 * a.DK * npad * 4;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fa_lrk_kernel, dim3(a.heads, a.B), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// FABlock2D core: every channel plane P (H x W) of head h becomes
+//     Y = Kx[b,h] . (P . Ky[b,h]^T)          (then InstanceNorm over the plane)
+// One wave per plane at a time.  U = P Ky^T keeps the plane row j in registers
+// and the column l on lanes, i.e. exactly the B-operand layout of the second
+// product Y = Kx U, so U never leaves registers; Y has columns on lanes ->
+// 128-byte row-segment stores.  InstanceNorm (biased var) is computed from the
+// accumulator registers (two-pass, exact) and applied before the store.
+// ===========================================================================
+template <int HT, int WT>
+__global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int planes_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = HT * 32 + 1, WP = WT * 32 + 1;
+    float* Kxs = reinterpret_cast<float*>(smem);          // [HT*32][HP]
+    float* Kys = Kxs + HT * 32 * HP;                      // [WT*32][WP]
+    float* Pall = Kys + WT * 32 * WP;                     // 4 x [HT*32][WP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int H = a.H, W = a.W, C = a.C;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
+    const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
+    for (int i = tid; i < HT * 32 * (HT * 32); i += 256) {
+        const int r = i / (HT * 32), c = i - r * (HT * 32);
+        Kxs[r * HP + c] = (r < H && c < H) ? kxg[(long)r * H + c] : 0.0f;
+    }
+    for (int i = tid; i < WT * 32 * (WT * 32); i += 256) {
+        const int r = i / (WT * 32), c = i - r * (WT * 32);
+        Kys[r * WP + c] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
+    }
+    float* Ps = Pall + wave * (HT * 32 * WP);
+    const int c_begin = blockIdx.x * planes_per_block;
+    const int iters = (planes_per_block + 3) / 4;
+    const float inv_cnt = 1.0f / (float)(H * W);
+    for (int it_ = 0; it_ < iters; ++it_) {
+        const int cl = it_ * 4 + wave;
+        const int c = c_begin + cl;
+        const bool active = (cl < planes_per_block) && (c < C);
+        __syncthreads();   // Kxs/Kys ready (first pass); previous plane of every wave consumed
+        if (active) {
+            const float* pg = a.u + (((long)b * a.heads + h) * C + c) * H * W;
+            for (int i = lane; i < HT * 32 * (WT * 32); i += 64) {
+                const int r = i / (WT * 32), cc = i - r * (WT * 32);
+                Ps[r * WP + cc] = (r < H && cc < W) ? pg[(long)r * W + cc] : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+        f32x16 Y[HT][WT];
+#pragma unroll
+        for (int i = 0; i < HT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[i][j][r] = 0.0f;
+        const int kpairs = (W + 1) >> 1;
+#pragma unroll
+        for (int lt = 0; lt < WT; ++lt) {
+            f32x16 U[HT];
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) U[jt][r] = 0.0f;
+            const float* kyp = Kys + (lt * 32 + l31) * WP + kh;
+            const float* pp = Ps + l31 * WP + kh;
+#pragma unroll 4
+            for (int kk = 0; kk < kpairs; ++kk) {
+                const float bv = kyp[2 * kk];
+#pragma unroll
+                for (int jt = 0; jt < HT; ++jt)
+                    U[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pp[jt * 32 * WP + 2 * kk], bv, U[jt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < HT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Y[it][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            Kxs[(it * 32 + l31) * HP + jt * 32 + drow(r, kh)], U[jt][r], Y[it][lt], 0, 0, 0);
+        }
+        float mean = 0.0f, rstd = 1.0f;
+        if (a.instnorm) {
+            float s = 0.0f;
+#pragma unroll
+            for (int it = 0; it < HT; ++it)
+#pragma unroll
+                for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool v = (it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W);
+                        s += v ? Y[it][lt][r] : 0.0f;
+                    }
+            mean = wave_sum(s) * inv_cnt;
+            float q = 0.0f;
+#pragma unroll
+            for (int it = 0; it < HT; ++it)
+#pragma unroll
+                for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool v = (it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W);
+                        const float d = Y[it][lt][r] - mean;
+                        q += v ? d * d : 0.0f;
+                    }
+            rstd = 1.0f / sqrtf(wave_sum(q) * inv_cnt + a.eps);
+        }
+        float* og = a.out + (((long)b * a.heads + h) * C + c) * H * W;
+#pragma unroll
+        for (int it = 0; it < HT; ++it)
+#pragma unroll
+            for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = it * 32 + drow(r, kh), l = lt * 32 + l31;
+                    if (i < H && l < W) og[(long)i * W + l] = (Y[it][lt][r] - mean) * rstd;
+                }
+    }
+}
+
+size_t fa_sandwich_lds_bytes(int H, int W) {
+    const int HT = (H + 31) / 32, WT = (W + 31) / 32;
+    const size_t HP = HT * 32 + 1, WP = WT * 32 + 1;
+    return (HT * 32 * HP + WT * 32 * WP + 4 * HT * 32 * WP) * 4;
+}
+
+template <int HT, int WT>
+static hipError_t launch_fa_sandwich_t(const FaSandwichArgs& a, hipStream_t s) {
+    const size_t lds = fa_sandwich_lds_bytes(a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // planes per block: enough blocks to fill the chip, few enough to amortise the Kx/Ky staging
+    int ppb = 16;
+    while (ppb > 4 && (long)a.B * a.heads * ((a.C + ppb - 1) / ppb) < 512) ppb >>= 1;
+    dim3 grid((a.C + ppb - 1) / ppb, a.heads, a.B);
+    hipLaunchKernelGGL((fa_sandwich_kernel<HT, WT>), grid, dim3(256), lds, s, a, ppb);
+    return hipGetLastError();
+}
+
+hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s) {
+    const int HT = (a.H + 31) / 32, WT = (a.W + 31) / 32;
+    if (HT == 1 && WT == 1) return launch_fa_sandwich_t<1, 1>(a, s);
+    if (HT == 1 && WT == 2) return launch_fa_sandwich_t<1, 2>(a, s);
+    if (HT == 2 && WT == 2) return launch_fa_sandwich_t<2, 2>(a, s);
+    if (HT == 2 && WT == 3) return launch_fa_sandwich_t<2, 3>(a, s);
+    if (HT == 2 && WT == 1) return launch_fa_sandwich_t<2, 1>(a, s);
+    return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+hipError_t init_kernels() {
+    hipError_t e;
+    const int maxlds = 160 * 1024;
+#define LNS_SET_LDS(k)                                                                            \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
+    if (e != hipSuccess) return e;
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4>))
+    LNS_SET_LDS((fa_sandwich_kernel<1, 1>))
+    LNS_SET_LDS((fa_sandwich_kernel<1, 2>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 2>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 3>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 1>))
+    LNS_SET_LDS(fa_lrk_kernel)
+    LNS_SET_LDS(fa_pool_kernel)
+    LNS_SET_LDS(fa_reducer_kernel)
+#undef LNS_SET_LDS
+    return hipSuccess;
+}
+
+}  // namespace lns

@@ -1,0 +1,316 @@
+"""Drop-in `nn.Module` surface of the hot path.
+
+The classes here keep the reference's constructor arguments, method names,
+attribute names and state_dict keys/shapes
+    SimpleAutoencoder(args).encode/decode/forward/load_checkpoint   modules/autoencoder2d.py:160-186
+    SimpleCNN(latent_dim, [cond_emb_dim,] prop_n_block, prop_n_embd, dilation)(z[, param])
+                                                                   train_stage2_ns2d.py:56-87
+    LatentDynamics(args).x_to_z/z_to_x/predict/load_autoencoder     train_stage2_ns2d.py:90-158
+but hold NO arithmetic: the parameter tree is generated from the engine's
+parameter table (the single definition of the architecture lives in
+csrc/lns_model.cpp) and every call runs the HIP engine through the C ABI.
+They are inference-only (the reference wraps this path in torch.no_grad()).
+"""
+import math
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as _engine
+from ._lib import (LNS_AE_HALF_PERIODIC, LNS_AE_NONE, LNS_AE_NONSQUARED, LNS_AE_SQUARE,
+                   LNS_PAD_CIRCULAR, LNS_PAD_ZEROS, LNS_PROP_CONDITIONAL, LNS_PROP_NONE,
+                   LNS_PROP_PLAIN, LnsError)
+
+
+class _Node(nn.Module):
+    """Parameter container mirroring one reference sub-module."""
+
+    def forward(self, *a, **k):
+        raise LnsError("sub-modules of the drop-in hold parameters only; call the owning "
+                       "SimpleAutoencoder / SimpleCNN / LatentDynamics")
+
+
+def _init_value(key, shape, sibling_weight_shape):
+    """PyTorch-default-like initial values (reference constructors rely on
+    nn.Conv2d/nn.Linear defaults, SABlock._init_weights basics.py:358-369,
+    zero_module cond_utils.py:12-16, spectral weights basics.py:119-124)."""
+    leaf = key.rsplit(".", 1)[-1]
+    t = torch.empty(shape, dtype=torch.float32)
+    sa = any(s in key for s in (".to_q.", ".to_k.", ".to_v.", ".proj_out."))
+    zero = (".cond_conv1.2." in key) or (".cond_conv2.3." in key)
+    if leaf == "inv_freq":
+        dim = 2 * shape[0]
+        return 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    if zero:
+        return t.zero_()
+    if leaf == "pe":
+        return t.normal_(0.0, 0.02)
+    if leaf in ("weights1", "weights2") and len(shape) == 5:
+        return t.uniform_(0, 1).mul_(1.0 / (shape[0] * shape[1]))
+    if len(shape) >= 2:
+        if sa:
+            return t.normal_(0.0, 0.02)
+        fan_in = int(np.prod(shape[1:]))
+        b = 1.0 / math.sqrt(fan_in)
+        return t.uniform_(-b, b)
+    if leaf == "weight":
+        return t.fill_(1.0)
+    if sibling_weight_shape is not None and len(sibling_weight_shape) >= 2 and not sa:
+        b = 1.0 / math.sqrt(int(np.prod(sibling_weight_shape[1:])))
+        return t.uniform_(-b, b)
+    return t.zero_()
+
+
+def _grow_tree(root, table, strip=""):
+    shapes = {k: s for k, s, _ in table}
+    for key, shape, is_buffer in table:
+        assert key.startswith(strip), (key, strip)
+        parts = key[len(strip):].split(".")
+        node = root
+        for p in parts[:-1]:
+            if not hasattr(node, p):
+                node.add_module(p, _Node())
+            node = getattr(node, p)
+        sib = shapes.get(key.rsplit(".", 1)[0] + ".weight")
+        val = _init_value(key, shape, sib)
+        if is_buffer:
+            node.register_buffer(parts[-1], val)
+        else:
+            node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
+
+
+class _Hosted(nn.Module):
+    """A module whose forward runs on an lns engine.  The engine belongs to the
+    outermost constructed object (`_owner`); nested views share it."""
+
+    def _init_host(self, cfg=None, owner=None, prefix=""):
+        object.__setattr__(self, "_owner_ref", owner if owner is not None else self)
+        object.__setattr__(self, "_prefix", prefix)
+        if owner is None:
+            object.__setattr__(self, "_eng", _engine.Engine(cfg))
+            object.__setattr__(self, "_sig", None)
+
+    @property
+    def _owner(self):
+        return self._owner_ref
+
+    def _engine(self, like):
+        """Engine with the current weights resident on `like`'s device."""
+        own = self._owner
+        if not isinstance(like, torch.Tensor) or not like.is_cuda:
+            raise LnsError("the LNS drop-in runs on HIP device tensors only (input is on %s); there is "
+                           "no CPU fallback -- use the reference implementation on CPU"
+                           % (getattr(like, "device", "host")))
+        sd = own.state_dict()
+        dev = like.device.index if like.device.index is not None else torch.cuda.current_device()
+        sig = (dev, tuple((t.data_ptr(), t._version) for t in sd.values()))
+        if own._sig != sig:
+            own._eng.load_weights({k: v.detach().to("cpu", torch.float32).numpy() for k, v in sd.items()}, dev)
+            object.__setattr__(own, "_sig", sig)
+        return own._eng
+
+
+# ---------------------------------------------------------------------------
+class SimpleAutoencoder(_Hosted):
+    """modules/autoencoder2d{,_nonsquared,_half_periodic}.py `SimpleAutoencoder`."""
+    _ae_kind = LNS_AE_SQUARE
+
+    def __init__(self, args, _owner=None, _prefix=""):
+        super().__init__()
+        self.args = args
+        if _owner is None:
+            cfg = _engine.make_config(args, ae_kind=self._ae_kind, prop_kind=LNS_PROP_NONE)
+            self._init_host(cfg=cfg)
+            _grow_tree(self, self._eng.params)
+        else:
+            self._init_host(owner=_owner, prefix=_prefix)
+            _grow_tree(self, [p for p in _owner._eng.params if p[0].startswith(_prefix)], strip=_prefix)
+
+    @torch.no_grad()
+    def encode(self, x):
+        return self._engine(x).encode(x)
+
+    @torch.no_grad()
+    def decode(self, z):
+        return self._engine(z).decode(z)
+
+    def forward(self, x):
+        return self.decode(self.encode(x))
+
+    def load_checkpoint(self, path, device=None):
+        ckpt = torch.load(path, map_location=device)
+        self.load_state_dict(ckpt, strict=True)
+
+
+class SimpleAutoencoderNonSquared(SimpleAutoencoder):
+    _ae_kind = LNS_AE_NONSQUARED
+
+
+class SimpleAutoencoderHalfPeriodic(SimpleAutoencoder):
+    _ae_kind = LNS_AE_HALF_PERIODIC
+
+
+# ---------------------------------------------------------------------------
+class SimpleCNN(_Hosted):
+    """Latent propagator `SimpleCNN` of the stage-2 scripts.  `pad` = (mode_y, mode_x)."""
+    _prop_kind = LNS_PROP_PLAIN
+    _pad = (LNS_PAD_CIRCULAR, LNS_PAD_CIRCULAR)
+
+    def __init__(self, latent_dim, prop_n_block, prop_n_embd, dilation=2, _owner=None, _prefix="",
+                 _cond_emb_dim=None):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.prop_n_block = prop_n_block
+        self.prop_n_embd = prop_n_embd
+        if _owner is None:
+            a = types.SimpleNamespace(latent_dim=latent_dim, prop_n_block=prop_n_block, prop_n_embd=prop_n_embd,
+                                      dilation=dilation, cond_emb_dim=_cond_emb_dim or latent_dim)
+            cfg = _engine.make_config(a, ae_kind=LNS_AE_NONE, prop_kind=self._prop_kind, prop_pad=self._pad)
+            self._init_host(cfg=cfg)
+            _grow_tree(self, self._eng.params)
+        else:
+            self._init_host(owner=_owner, prefix=_prefix)
+            _grow_tree(self, [p for p in _owner._eng.params if p[0].startswith(_prefix)], strip=_prefix)
+
+    @torch.no_grad()
+    def forward(self, z, param=None):
+        return self._engine(z).propagate(z, param)
+
+
+class SimpleCNNHalfPeriodic(SimpleCNN):       # train_stage2_SW.py:56-87 (periodic_direction='x')
+    _pad = (LNS_PAD_ZEROS, LNS_PAD_CIRCULAR)
+
+
+class SimpleCNNZeros(SimpleCNN):              # train_stage2_twophase.py:56-87 (padding_mode='zeros')
+    _pad = (LNS_PAD_ZEROS, LNS_PAD_ZEROS)
+
+
+class SimpleCNNConditional(SimpleCNN):        # train_stage2_twophase_conditional.py:78-121
+    _prop_kind = LNS_PROP_CONDITIONAL
+    _pad = (LNS_PAD_ZEROS, LNS_PAD_ZEROS)
+
+    def __init__(self, latent_dim, cond_emb_dim, prop_n_block, prop_n_embd, dilation=2, _owner=None, _prefix=""):
+        super().__init__(latent_dim, prop_n_block, prop_n_embd, dilation, _owner=_owner, _prefix=_prefix,
+                         _cond_emb_dim=cond_emb_dim)
+        self.cond_emb_dim = cond_emb_dim
+
+    @torch.no_grad()
+    def forward(self, z, param):
+        return self._engine(z).propagate(z, param)
+
+
+# ---------------------------------------------------------------------------
+class LatentDynamics(_Hosted):
+    """`LatentDynamics` of train_stage2_ns2d.py:90-158 (and the SW / two-phase variants)."""
+    _family = "ns2d"
+    _ae_cls = SimpleAutoencoder
+    _prop_cls = SimpleCNN
+    _ae_attr = "vq_ae"
+    _conditional = False
+
+    def __init__(self, args):
+        super().__init__()
+        if getattr(args, "family", None) is None:
+            args = types.SimpleNamespace(**vars(args))
+            args.family = self._family
+        self.args = args
+        self.latent_resolution = args.latent_resolution
+        self.latent_dim = args.latent_dim
+        cfg = _engine.make_config(args, ae_kind=self._ae_cls._ae_kind, prop_kind=self._prop_cls._prop_kind,
+                                  ae_prefix=self._ae_attr + ".", prop_prefix="propagator.",
+                                  prop_pad=self._prop_cls._pad)
+        self._init_host(cfg=cfg)
+        ae = self._ae_cls(args, _owner=self, _prefix=self._ae_attr + ".")
+        self.add_module(self._ae_attr, ae)
+        if self._conditional:
+            prop = self._prop_cls(args.latent_dim, args.latent_dim, args.prop_n_block, args.prop_n_embd,
+                                  args.dilation, _owner=self, _prefix="propagator.")
+        else:
+            prop = self._prop_cls(args.latent_dim, args.prop_n_block, args.prop_n_embd, args.dilation,
+                                  _owner=self, _prefix="propagator.")
+        self.propagator = prop
+
+    @property
+    def _ae(self):
+        return getattr(self, self._ae_attr)
+
+    def load_autoencoder(self, args):
+        print("Loading pretrained autoencoder from {}".format(args.pretrained_checkpoint_path))
+        self._ae.load_checkpoint(args.pretrained_checkpoint_path, device=getattr(args, "device", None))
+        print("Pretrained autoencoder loaded successfully")
+        for p in self._ae.parameters():
+            p.requires_grad = False
+        self._ae.eval()
+
+    @torch.no_grad()
+    def x_to_z(self, x):
+        return self._ae.encode(x)
+
+    @torch.no_grad()
+    def z_to_x(self, z):
+        return self._ae.decode(z)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("teacher-forced training rollout (train_stage2_ns2d.py:126-141) needs "
+                                  "autograd and is outside the accelerated inference path")
+
+    @staticmethod
+    def _fields(x):
+        # SW / two-phase loaders hand [B,1,C,H,W]; the reference squeezes (B=1 safe here)
+        if x.dim() == 5 and x.shape[1] == 1:
+            x = x[:, 0]
+        return x
+
+    @torch.no_grad()
+    def predict(self, x, steps, *rest, to_x=False, return_latents=False):
+        """predict(x, steps, to_x=False) -- conditional: predict(x, steps, param, to_x=False)."""
+        param = None
+        if self._conditional:
+            if not rest:
+                raise TypeError("predict() missing required argument: 'param'")
+            param, rest = rest[0], rest[1:]
+        if rest:
+            to_x = rest[0]
+        x = self._fields(x)
+        return self._engine(x).rollout(x, steps, param=param, to_x=to_x, return_latents=return_latents)
+
+
+class LatentDynamicsSW(LatentDynamics):                 # train_stage2_SW.py:90-159
+    _family = "sw_half_periodic"
+    _ae_cls = SimpleAutoencoderHalfPeriodic
+    _prop_cls = SimpleCNNHalfPeriodic
+
+
+class LatentDynamicsSWNonSquared(LatentDynamics):       # BASELINE config 3 (SW through autoencoder2d_nonsquared)
+    _family = "sw_nonsquared"
+    _ae_cls = SimpleAutoencoderNonSquared
+    _prop_cls = SimpleCNNHalfPeriodic
+
+
+class LatentDynamicsTwoPhase(LatentDynamics):           # train_stage2_twophase.py:90-159
+    _family = "twophase"
+    _ae_cls = SimpleAutoencoderNonSquared
+    _prop_cls = SimpleCNNZeros
+
+
+class LatentDynamicsTwoPhaseConditional(LatentDynamics):  # train_stage2_twophase_conditional.py:124-193
+    _family = "twophase_cond"
+    _ae_cls = SimpleAutoencoderNonSquared
+    _prop_cls = SimpleCNNConditional
+    _ae_attr = "ae"
+    _conditional = True
+
+
+FAMILY_CLASSES = {
+    "ns2d": LatentDynamics,
+    "sw_half_periodic": LatentDynamicsSW,
+    "sw_nonsquared": LatentDynamicsSWNonSquared,
+    "twophase": LatentDynamicsTwoPhase,
+    "twophase_cond": LatentDynamicsTwoPhaseConditional,
+}
+
+
+def build_dynamics(args):
+    return FAMILY_CLASSES[args.family](args)

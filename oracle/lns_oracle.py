@@ -179,6 +179,12 @@ class _Net:
     def __init__(self, sd, mode):
         self.sd = sd
         self.mode = mode  # (mode_y, mode_x) of the 'same' convs
+        self.trace = None  # optional {module prefix: output} record for layer-by-layer tests
+
+    def rec(self, name, val):
+        if self.trace is not None:
+            self.trace[name] = val
+        return val
 
     def has(self, k):
         return k in self.sd
@@ -194,7 +200,7 @@ class _Net:
         if pad is None:
             p = dil * (k - 1) // 2
             pad = (p, p, p, p)
-        return conv2d(x, w, b, stride, dil, pad, self.mode if mode is None else mode)
+        return self.rec(pfx, conv2d(x, w, b, stride, dil, pad, self.mode if mode is None else mode))
 
     # basics.GroupNorm wrapper: 32 groups, eps 1e-6  (modules/basics.py:18-24)
     def gn32(self, x, pfx):
@@ -211,7 +217,7 @@ def residual_block(net, x, pfx):
     h = net.conv(swish(net.gn32(h, pfx + ".block.3")), pfx + ".block.5")
     if net.has(pfx + ".channel_up.weight"):
         x = net.conv(x, pfx + ".channel_up")
-    return x + h
+    return net.rec(pfx, x + h)
 
 
 def hp_residual_block(net, x, pfx):
@@ -219,7 +225,7 @@ def hp_residual_block(net, x, pfx):
     skip = net.conv(x, pfx + ".channel_up") if net.has(pfx + ".channel_up.weight") else x
     h = net.conv(swish(net.gn32(x, pfx + ".norm_act1.norm_act.0")), pfx + ".conv1")
     h = net.conv(swish(net.gn32(h, pfx + ".norm_act2.norm_act.0")), pfx + ".conv2")
-    return h + skip
+    return net.rec(pfx, h + skip)
 
 
 def downsample_block(net, x, pfx):
@@ -267,7 +273,7 @@ def sa_block(net, x, pfx, heads):
     out = np.ascontiguousarray(out.transpose(0, 2, 1, 3)).reshape(B, n, heads * d)
     out = linear(out, sd[pfx + ".proj_out.weight"], sd[pfx + ".proj_out.bias"])
     out = x_in + out
-    return np.ascontiguousarray(out.transpose(0, 2, 1)).reshape(B, C, H, W)
+    return net.rec(pfx, np.ascontiguousarray(out.transpose(0, 2, 1)).reshape(B, C, H, W))
 
 
 def _rotary(t, inv_freq):
@@ -326,7 +332,7 @@ def fa_block(net, x, pfx, heads):
     h = groupnorm(u_phi, C, 1e-5)                       # InstanceNorm2d, no affine
     h = gelu(conv2d(h, sd[pfx + ".to_out.1.weight"]))
     h = conv2d(h, sd[pfx + ".to_out.3.weight"])
-    return h + u_skip
+    return net.rec(pfx, h + u_skip)
 
 
 def spectral_conv2d(sd, pfx, x, emb12=None):
@@ -412,7 +418,7 @@ class OracleAutoencoder:
         ch = a.encoder_channels
         idx = 0
         x = conv2d(x, net[p + "0.weight"], net[p + "0.bias"])          # 1x1
-        x = swish(x)
+        x = net.rec(p + "0", swish(x))      # engine fuses the Swish into this conv's epilogue
         idx = 2
         if self.kind == "hp":
             # autoencoder2d_half_periodic.py:120-139
@@ -448,7 +454,7 @@ class OracleAutoencoder:
             else:
                 x = residual_block(net, x, p + str(idx)); idx += 1
         x = swish(net.gn32(x, p + str(idx))); idx += 2
-        x = conv2d(x, net[p + f"{idx}.weight"], net[p + f"{idx}.bias"])
+        x = net.rec(p + str(idx), conv2d(x, net[p + f"{idx}.weight"], net[p + f"{idx}.bias"]))
         q = self.pfx + "quant_conv"
         return conv2d(x, net[q + ".weight"], net[q + ".bias"])
 
@@ -456,7 +462,7 @@ class OracleAutoencoder:
     def decode(self, z):
         a, net, p = self.args, self.net, self.pfx + "decoder.model."
         q = self.pfx + "post_quant_conv"
-        x = conv2d(z, net[q + ".weight"], net[q + ".bias"])
+        x = net.rec(q, conv2d(z, net[q + ".weight"], net[q + ".bias"]))
         ch = a.decoder_channels
         kind = self.kind
         heads = a.attn_heads if kind == "square" else a.decoder_attn_heads
@@ -536,7 +542,7 @@ class OraclePropagator:
         h = net.gn(x, p + ".ffn.0", 1)
         h = gelu(conv2d(h, net[p + ".ffn.1.weight"]))
         h = conv2d(h, net[p + ".ffn.3.weight"])
-        return x + h
+        return net.rec(p, x + h)
 
     def _cond_block(self, x, p, dil, cond_emb):
         """train_stage2_twophase_conditional.py:66-75"""
@@ -557,11 +563,11 @@ class OraclePropagator:
         h = net.gn(u, p + ".ffn.0", 1)
         h = gelu(conv2d(h, net[p + ".ffn.1.weight"]))
         h = conv2d(h, net[p + ".ffn.3.weight"])
-        return x + h
+        return net.rec(p, x + h)
 
     def forward(self, z, param=None):
         a, net, p = self.args, self.net, self.pfx
-        x = conv2d(z, net[p + "in_proj.weight"], net[p + "in_proj.bias"])
+        x = net.rec(p + "in_proj", conv2d(z, net[p + "in_proj.weight"], net[p + "in_proj.bias"]))
         if self.cond:
             sd = net.sd
             ce = fourier_embedding(np.asarray(param), a.latent_dim)

@@ -1,0 +1,230 @@
+"""Shared GPU parity checks (used by the -m gpu tests and tools/gpu_diag.py).
+
+Every check runs the HIP path through the C ABI (ctypes) and compares with the
+CPU oracle (oracle/, test infrastructure) or the committed golden fixtures.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+import lns_oracle
+from helpers import rel_l2
+from lns_amd import _lib
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _hp(a):
+    return np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), up=None, ss=False, act_in=0,
+              act_out=0, res=False, badd=False, bias=True, variant=-1, seed=0):
+    """Returns (rel_l2 error, output shape) of lns_op_conv2d vs the oracle composition."""
+    L = _lib.lib()
+    r = rng(seed)
+    x = r.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (r.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bv = r.standard_normal(Cout).astype(np.float32) * 0.1 if bias else None
+    if pad is None:
+        p = dil * (k - 1) // 2
+        pad = (p, p, p, p)
+    ssv = None
+    xin = x
+    if ss:
+        ssv = np.stack([1.0 + 0.2 * r.standard_normal((B, Cin)), 0.1 * r.standard_normal((B, Cin))], -1).astype(np.float32)
+        xin = x * ssv[:, :, 0][:, :, None, None] + ssv[:, :, 1][:, :, None, None]
+    if act_in == 1:
+        xin = lns_oracle.swish(xin)
+    elif act_in == 2:
+        xin = lns_oracle.gelu(xin)
+    Hv, Wv = H, W
+    if up is not None:
+        Hv, Wv = up
+        sch = 0.5 if Hv == 2 * H else 0.0
+        scw = 0.5 if Wv == 2 * W else 0.0
+        xin = lns_oracle.upsample_nearest(xin, Hv, Wv, sch, scw)
+    ref = lns_oracle.conv2d(xin, w, bv, stride, dil, pad, mode)
+    badd_v = None
+    if badd:
+        badd_v = r.standard_normal((B, Cout)).astype(np.float32)
+        ref = ref + badd_v[:, :, None, None]
+    if act_out == 1:
+        ref = lns_oracle.swish(ref)
+    elif act_out == 2:
+        ref = lns_oracle.gelu(ref)
+    res_v = None
+    if res:
+        res_v = r.standard_normal(ref.shape).astype(np.float32)
+        ref = ref + res_v
+    xd = _dev(x)
+    y = torch.full(ref.shape, float("nan"), dtype=torch.float32, device="cuda")
+    ssd = _dev(ssv) if ssv is not None else None
+    resd = _dev(res_v) if res_v is not None else None
+    baddd = _dev(badd_v) if badd_v is not None else None
+    rc = L.lns_op_conv2d(xd.data_ptr(), B, Cin, H, W, Hv, Wv, _hp(w), _hp(bv), Cout, k, stride, dil,
+                         pad[0], pad[1], pad[2], pad[3], mode[0], mode[1],
+                         ssd.data_ptr() if ssd is not None else None, act_in, act_out,
+                         resd.data_ptr() if resd is not None else None,
+                         baddd.data_ptr() if baddd is not None else None, y.data_ptr(), variant, _stream())
+    assert rc == 0, "lns_op_conv2d rc=%d" % rc
+    torch.cuda.synchronize()
+    out = y.cpu().numpy()
+    assert np.isfinite(out).all(), "non-finite / unwritten outputs"
+    return rel_l2(out, ref), ref.shape
+
+
+CONV_CASES = [
+    dict(B=2, Cin=64, Cout=64, H=32, W=32, k=3, mode=(1, 1)),
+    dict(B=2, Cin=64, Cout=64, H=32, W=32, k=3, mode=(0, 0)),
+    dict(B=2, Cin=64, Cout=64, H=24, W=48, k=3, mode=(0, 1)),
+    dict(B=2, Cin=64, Cout=64, H=24, W=48, k=3, mode=(1, 0)),
+    dict(B=2, Cin=128, Cout=128, H=16, W=16, k=3, dil=2, mode=(1, 1)),
+    dict(B=2, Cin=128, Cout=128, H=12, W=24, k=3, dil=3, mode=(0, 1)),
+    dict(B=2, Cin=128, Cout=128, H=7, W=15, k=3, dil=2, mode=(0, 0)),
+    dict(B=2, Cin=64, Cout=64, H=32, W=32, k=3, stride=2, pad=(1, 1, 1, 1), mode=(1, 1)),
+    dict(B=2, Cin=64, Cout=64, H=61, W=121, k=3, stride=2, pad=(0, 1, 0, 1), mode=(0, 0)),
+    dict(B=2, Cin=64, Cout=64, H=24, W=48, k=3, stride=2, pad=(1, 1, 1, 1), mode=(0, 1)),
+    dict(B=2, Cin=3, Cout=64, H=32, W=32, k=1, act_out=1),
+    dict(B=2, Cin=16, Cout=128, H=16, W=16, k=1),
+    dict(B=2, Cin=128, Cout=16, H=16, W=16, k=1, ss=True, act_in=1),
+    dict(B=2, Cin=64, Cout=3, H=64, W=64, k=1, ss=True, act_in=1),
+    dict(B=2, Cin=64, Cout=512, H=32, W=32, k=1, ss=True, bias=False),
+    dict(B=2, Cin=512, Cout=64, H=32, W=32, k=1, act_out=2, bias=False),
+    dict(B=2, Cin=64, Cout=64, H=16, W=16, k=3, up=(32, 32), mode=(1, 1)),
+    dict(B=2, Cin=64, Cout=64, H=28, W=60, k=3, up=(61, 121), mode=(0, 0)),
+    dict(B=2, Cin=64, Cout=128, H=32, W=32, k=3, ss=True, act_in=1, res=True),
+    dict(B=2, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act_in=2, act_out=2, badd=True),
+    dict(B=3, Cin=64, Cout=2048, H=1, W=64, k=1, bias=False),
+    dict(B=1, Cin=32, Cout=32, H=8, W=8, k=3, mode=(1, 1)),
+]
+for _v in range(6):   # every tile variant on the same problem
+    CONV_CASES.append(dict(B=2, Cin=64, Cout=(32 if _v == 5 else 128 if _v in (0, 2) else 64), H=32, W=32, k=3,
+                           mode=(1, 1), variant=_v))
+    CONV_CASES.append(dict(B=2, Cin=64, Cout=(32 if _v == 5 else 128 if _v in (0, 2) else 64), H=20, W=36, k=1,
+                           variant=_v, ss=True, act_in=1))
+
+
+def gn_case(B, C, HW, groups, eps, premul=False, seed=0):
+    L = _lib.lib()
+    r = rng(seed)
+    x = (r.standard_normal((B, C, HW)) * 1.5 + 0.7).astype(np.float32)
+    g = (1 + 0.1 * r.standard_normal(C)).astype(np.float32)
+    b = (0.1 * r.standard_normal(C)).astype(np.float32)
+    pm = (1 + 0.3 * r.standard_normal((B, C))).astype(np.float32) if premul else None
+    xin = x * pm[:, :, None] if premul else x
+    ref = lns_oracle.groupnorm(xin.reshape(B, C, HW, 1), groups, eps, g, b).reshape(B, C, HW)
+    ss = torch.empty((B, C, 2), dtype=torch.float32, device="cuda")
+    xd = _dev(x)
+    pmd = _dev(pm) if premul else None
+    rc = L.lns_op_groupnorm_stats(xd.data_ptr(), B, C, HW, groups, eps, _hp(g), _hp(b),
+                                  pmd.data_ptr() if premul else None, ss.data_ptr(), _stream())
+    assert rc == 0
+    s = ss.cpu().numpy()
+    out = x * s[:, :, 0:1] + s[:, :, 1:2]
+    return rel_l2(out, ref)
+
+
+def attention_case(B, heads, D, n, seed=0):
+    L = _lib.lib()
+    r = rng(seed)
+    qkv = r.standard_normal((B, 3, heads, D, n)).astype(np.float32)
+    q = np.ascontiguousarray(qkv[:, 0].transpose(0, 1, 3, 2))  # b h n d
+    k = np.ascontiguousarray(qkv[:, 1].transpose(0, 1, 3, 2))
+    v = np.ascontiguousarray(qkv[:, 2].transpose(0, 1, 3, 2))
+    scale = float(D) ** -0.5
+    attn = lns_oracle.softmax_rows(lns_oracle.bmm(q, k, transB=True), scale)
+    ref = lns_oracle.bmm(attn, v).transpose(0, 1, 3, 2)  # b h d n
+    qd = _dev(qkv)
+    o = torch.full((B, heads, D, n), float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.lns_op_attention(qd.data_ptr(), B, heads, D, n, scale, o.data_ptr(), _stream())
+    assert rc == 0
+    out = o.cpu().numpy()
+    assert np.isfinite(out).all()
+    return rel_l2(out, ref)
+
+
+def sandwich_case(B, heads, C, H, W, instnorm=True, seed=0):
+    L = _lib.lib()
+    r = rng(seed)
+    u = r.standard_normal((B, heads * C, H, W)).astype(np.float32)
+    kx = (r.standard_normal((B, heads, H, H)) / np.sqrt(H)).astype(np.float32)
+    ky = (r.standard_normal((B, heads, W, W)) / np.sqrt(W)).astype(np.float32)
+    ref = lns_oracle.fa_contract(u, kx, ky, heads)
+    if instnorm:
+        ref = lns_oracle.groupnorm(ref, heads * C, 1e-5)
+    ud, kxd, kyd = _dev(u), _dev(kx), _dev(ky)
+    o = torch.full(u.shape, float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.lns_op_fa_sandwich(ud.data_ptr(), kxd.data_ptr(), kyd.data_ptr(), B, heads, C, H, W, 1e-5,
+                              int(instnorm), o.data_ptr(), _stream())
+    assert rc == 0
+    out = o.cpu().numpy()
+    assert np.isfinite(out).all()
+    return rel_l2(out, ref)
+
+
+def build_models(args, weight_seed):
+    """(drop-in model on cuda, oracle) with identical deterministic weights."""
+    from helpers import synthetic_state_dict
+    from lns_amd import dropin
+    model = dropin.build_dynamics(args)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synthetic_state_dict(shapes, weight_seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    orc = lns_oracle.OracleDynamics(args, sd)
+    return model, orc
+
+
+def layer_trace_compare(args, weight_seed, x, param=None):
+    """Runs encode / one propagator step / decode with the engine's layer trace on and
+    returns [(stage, layer name, rel_l2 vs oracle)] for every layer both sides know."""
+    model, orc = build_models(args, weight_seed)
+    rows = []
+    xd = _dev(x)
+    pd = _dev(param) if param is not None else None
+    eng = model._engine(xd)
+    # oracle with recording
+    orc.ae.net.trace = {}
+    z_ref = orc.x_to_z(x)
+    enc_ref = dict(orc.ae.net.trace)
+    orc.prop.net.trace = {}
+    z1_ref = orc.prop.forward(z_ref, param)
+    prop_ref = dict(orc.prop.net.trace)
+    orc.ae.net.trace = {}
+    y_ref = orc.z_to_x(z1_ref)
+    dec_ref = dict(orc.ae.net.trace)
+    eng.trace_enable(True)
+    z = eng.encode(xd)
+    torch.cuda.synchronize()
+    for name, a in eng.trace():
+        if name in enc_ref and enc_ref[name].shape == a.shape:
+            rows.append(("encode", name, rel_l2(a, enc_ref[name])))
+    rows.append(("encode", "OUT z0", rel_l2(z.cpu().numpy(), z_ref)))
+    eng.trace_enable(True)
+    z1 = eng.propagate(_dev(z_ref), pd)
+    torch.cuda.synchronize()
+    for name, a in eng.trace():
+        if name in prop_ref and prop_ref[name].shape == a.shape:
+            rows.append(("propagate", name, rel_l2(a, prop_ref[name])))
+    rows.append(("propagate", "OUT z1", rel_l2(z1.cpu().numpy(), z1_ref)))
+    eng.trace_enable(True)
+    y = eng.decode(_dev(z1_ref))
+    torch.cuda.synchronize()
+    for name, a in eng.trace():
+        if name in dec_ref and dec_ref[name].shape == a.shape:
+            rows.append(("decode", name, rel_l2(a, dec_ref[name])))
+    rows.append(("decode", "OUT y", rel_l2(y.cpu().numpy(), y_ref)))
+    eng.trace_enable(False)
+    return rows

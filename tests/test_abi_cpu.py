@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol of include/lns.h,
+and its parameter table reproduces the reference's state_dict keys and shapes."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from helpers import ROOT, load_golden, manifest, case_args
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "lns.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lns_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lns_amd import _lib
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for s in declared:
+        assert hasattr(L, s), "missing export: " + s
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from lns_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblns_hip.so")
+    with pytest.raises(_lib.LnsLibraryError):
+        _lib.lib()
+
+
+@pytest.mark.parametrize("case", sorted(manifest().keys()))
+def test_param_table_matches_reference_state_dict(case):
+    from lns_amd import engine
+    meta, _ = load_golden(case)
+    args = case_args(meta)
+    aep = "ae." if args.family == "twophase_cond" else "vq_ae."
+    got = engine.param_shapes(args, ae_prefix=aep, prop_prefix="propagator.")
+    ref = {k: tuple(v) for k, v in manifest()[case].items()}
+    assert set(got) == set(ref)
+    for k in ref:
+        assert tuple(got[k]) == ref[k], k
+
+
+def test_dropin_state_dict_and_cpu_refusal():
+    import torch
+    from lns_amd import config, dropin
+    m = dropin.build_dynamics(config.preset("ns2d_mini"))
+    ref = {k: tuple(v) for k, v in manifest()["ns2d_mini"].items()}
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == ref
+    assert hasattr(m, "vq_ae") and hasattr(m, "propagator")
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(Exception) as ei:   # product path never falls back to CPU
+        m.predict(torch.zeros(2, 2, 32, 32), 2, to_x=True)
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_bad_config_is_an_error_not_a_crash():
+    from lns_amd import config, engine, _lib
+    args = config.preset("ns2d_mini", latent_resolution=8)   # violates the log2 assert of autoencoder2d.py:26
+    with pytest.raises(_lib.LnsError):
+        engine.param_shapes(args, ae_prefix="vq_ae.", prop_prefix="propagator.")

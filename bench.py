@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rollout-steps/sec (encode + N latent steps + decode every step),
+NS2d 128x128 3-channel, 64-step rollout, batch 64 per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full `LatentDynamics.predict(x, T=64, to_x=True)` over one batch
+(= B*T trajectory-steps).  Inputs are resident in HBM before the timed region; the
+timed region is bracketed by barrier + torch.cuda.synchronize() and the MAX over
+ranks is taken.  For N > 1 trajectories are sharded over ranks (weak scaling: B per
+GPU fixed, no data-path collective) and the decoded shards are all-gathered over
+RCCL in step blocks, overlapped with the remaining rollout.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+FLOP_PER_TRAJ_STEP = 5.926e9        # 0.732 propagate + 5.194 decode
+FLOP_ENCODE = 5.385e9
+
+
+def build_model(preset, device):
+    from helpers import synthetic_state_dict
+    from lns_amd import config, dropin
+    args = config.preset(preset)
+    model = dropin.build_dynamics(args)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synthetic_state_dict(shapes, 1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return args, model.to(device), sd
+
+
+def cpu_baseline(args, sd, B, T):
+    """The CPU oracle (port of the reference path) timed on this box's host cores on a
+    bounded sample of the same workload.  Reported, never the thing measured above."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lns_oracle
+    from lns_amd import filler
+    x = filler.normal("xcpu", (B, args.in_channels, args.Ly, args.Lx), 3)
+    orc = lns_oracle.OracleDynamics(args, sd)
+    orc.predict(x[:1], 1, to_x=True)            # warm the pages / thread pool
+    t0 = time.perf_counter()
+    orc.predict(x, T, to_x=True)
+    dt = time.perf_counter() - t0
+    return dict(value=B * T / dt, unit="trajectory-steps/s", cores=lns_oracle.num_threads(), kind="port",
+                sample="NS2d 128x128x3, B=%d, T=%d, predict(to_x=True), %.1f s" % (B, T, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="trajectories per GPU")
+    ap.add_argument("--rollout", type=int, default=64, help="latent rollout length T")
+    ap.add_argument("--preset", default="ns2d_128")
+    ap.add_argument("--gather-chunk", type=int, default=16, help="step-block size of the overlapped all-gather")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif a.gpus != 1:
+        print("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE unset); running 1 GPU" % a.gpus,
+              file=sys.stderr)
+    n_gpus = world
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from lns_amd import filler
+    args, model, sd = build_model(a.preset, dev)
+    B, T = a.batch, a.rollout
+    # each rank owns its own contiguous shard of the global batch (rank-dependent seed)
+    x = torch.from_numpy(filler.normal("xbench-%d" % rank, (B, args.in_channels, args.Ly, args.Lx), 5)).to(dev)
+    eng = model._engine(x)
+    C, H, W = eng.latent_shape()
+    out = torch.empty((B, T, args.in_channels, args.Ly, args.Lx), dtype=torch.float32, device=dev)
+    gather = world > 1 and not a.no_gather
+    chunk = max(1, min(a.gather_chunk, T))
+    if gather:
+        comm_stream = torch.cuda.Stream(device=dev)
+        n_chunks = (T + chunk - 1) // chunk
+        chunk_bufs = [torch.empty((B, min(chunk, T - i * chunk), args.in_channels, args.Ly, args.Lx),
+                                  dtype=torch.float32, device=dev) for i in range(n_chunks)]
+        gathered = [torch.empty((world,) + tuple(cb.shape), dtype=torch.float32, device=dev) for cb in chunk_bufs]
+
+    def one_pass():
+        if not gather:
+            eng.rollout(x, T, to_x=True, out=out)
+            return
+        # chunked rollout; each finished step block is all-gathered on a side stream
+        z = eng.encode(x)
+        works = []
+        for i, cb in enumerate(chunk_bufs):
+            _, z = eng.rollout_latent(z, cb.shape[1], to_x=True, out=cb)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                works.append(dist.all_gather_into_tensor(gathered[i], cb, async_op=True))
+        for w in works:
+            w.wait()
+        torch.cuda.current_stream().wait_stream(comm_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_pass()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    traj_steps = float(n_gpus) * B * T * a.steps
+    value = traj_steps / dt
+
+    result = {
+        "metric": "rollout-steps/sec (encode+N latent steps+decode), NS2d 128^2 3-ch",
+        "value": value, "unit": "trajectory-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded N(0,1) fields, deterministic random-init weights)",
+        "config": {"workload": "NS2d 128x128 3-channel, %d-step latent rollout, batch=%d per GPU "
+                               "(BASELINE.json configs[1])" % (T, B),
+                   "preset": a.preset, "batch_per_gpu": B, "rollout_steps": T, "global_batch": B * n_gpus,
+                   "parallelism": "trajectory-sharded x%d%s" % (n_gpus, ", overlapped all-gather" if gather else "")},
+        "batch_steps_per_s": value / B,
+        "path_tflops_per_gpu": (FLOP_PER_TRAJ_STEP * B * T + FLOP_ENCODE * B) * a.steps / dt / 1e12,
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # per-kernel-class HIP-event timing of one more pass on the same stream (events are
+        # recorded around every launch inside the engine; kept out of `value`'s timed region)
+        eng.timing_enable(True)
+        eng.rollout(x, T, to_x=True, out=out)
+        torch.cuda.synchronize()
+        tm = eng.timing()
+        eng.timing_enable(False)
+        k = tm.get("conv3x3_mfma")
+        if k:
+            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            result["roofline"] = {
+                "kernel": "conv_mfma_kernel (3x3 implicit GEMM, fp32 MFMA)", "bound": "mfma",
+                "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None, "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
+                "algorithmic_flop_per_launch": k["flops"] / k["launches"],
+            }
+        tot = sum(v["ms"] for v in tm.values())
+        result["kernel_classes"] = {n: {"ms": round(v["ms"], 3), "share": round(v["ms"] / tot, 4),
+                                        "launches": v["launches"],
+                                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                        "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+                                    for n, v in sorted(tm.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, sd, 4, 8)
+        result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

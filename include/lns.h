@@ -148,6 +148,12 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
                 float* out, float* latents_out, void* workspace, size_t workspace_bytes,
                 void* stream);
 
+/* The same loop started from a latent state (chunked rollouts, e.g. to overlap the
+ * gather of finished step blocks with the remaining steps): z_in [B,latent_dim,h,w] ->
+ * out [B,T,...]; z_last (nullable) receives the latent after step T. */
+int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int B, int T, int to_x,
+                       float* out, float* z_last, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- diagnostics -------------------------------------------------------- */
 /* Layer trace: when enabled the run calls synchronise after every reference
  * module boundary and keep a host copy of its output (tests compare them with

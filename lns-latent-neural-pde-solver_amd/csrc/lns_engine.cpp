@@ -591,7 +591,7 @@ static int finalize_weights(lns_engine* e, int device) {
     }
     HIPCHK(e, hipSetDevice(device));
     HIPCHK(e, init_kernels());
-    if (e->d_weights) { hipFree(e->d_weights); e->d_weights = nullptr; }
+    if (e->d_weights) { (void)hipFree(e->d_weights); e->d_weights = nullptr; }
     HIPCHK(e, hipMalloc(reinterpret_cast<void**>(&e->d_weights), std::max<size_t>(off, 64) * 4));
     HIPCHK(e, hipMemcpy(e->d_weights, host.data(), off * 4, hipMemcpyHostToDevice));
     e->weights_floats = off;
@@ -599,7 +599,7 @@ static int finalize_weights(lns_engine* e, int device) {
     e->finalized = true;
     // plans hold weight offsets only, but rotary tables depend on inv_freq: drop cached plans
     for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans}) {
-        for (auto& kv : *m) if (kv.second.d_consts) hipFree(kv.second.d_consts);
+        for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
         m->clear();
     }
     return LNS_OK;
@@ -765,10 +765,10 @@ struct Runner {
         }
         for (EvPair& ev : evs) {
             float ms = 0;
-            hipEventElapsedTime(&ms, ev.a, ev.b);
+            (void)hipEventElapsedTime(&ms, ev.a, ev.b);
             TimeRec& t = e->timing[ev.cls];
             t.ms += ms; t.launches += 1; t.flops += ev.op->flops; t.bytes += ev.op->bytes;
-            hipEventDestroy(ev.a); hipEventDestroy(ev.b);
+            (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
         }
         evs.clear();
         return LNS_OK;
@@ -830,8 +830,8 @@ int lns_create(const lns_config* cfg, lns_engine** out) {
 void lns_destroy(lns_engine* e) {
     if (!e) return;
     for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans})
-        for (auto& kv : *m) if (kv.second.d_consts) hipFree(kv.second.d_consts);
-    if (e->d_weights) hipFree(e->d_weights);
+        for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
+    if (e->d_weights) (void)hipFree(e->d_weights);
     delete e;
 }
 
@@ -940,36 +940,27 @@ int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, i
     return r.finish();
 }
 
-int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T, int to_x, float* out,
-                float* latents_out, void* ws, size_t ws_bytes, void* stream) {
-    if (!e || !x || !out || B <= 0 || T <= 0) return LNS_EINVAL;
-    if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
-    if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
-    WsLayout L; int rc;
-    if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
-    Plan *pe, *pp, *pd;
-    if ((rc = get_plan(e, PK_ENC, B, 0, 0, &pe))) return rc;
+// shared autoregressive loop: zcur -> T x (propagate ; decode)   (train_stage2_ns2d.py:147-156)
+static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param, int B, int T, int to_x, float* out,
+                        float* latents_out, float* z_last, const WsLayout& L, char* base) {
+    Plan *pp, *pd;
+    int rc;
     if ((rc = get_plan(e, PK_PROP, B, e->lat_H, e->lat_W, &pp))) return rc;
     if ((rc = get_plan(e, PK_DEC, B, 0, 0, &pd))) return rc;
     const lns_config& c = e->cfg;
     const long zper = (long)e->lat_C * e->lat_H * e->lat_W;
     const long xper = (long)c.in_channels * c.Ly * c.Lx;
-    char* base = static_cast<char*>(ws);
     float* zbuf[2] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + L.z_bytes)};
     char* arena = base + L.arena_off;
-    Runner r(e, static_cast<hipStream_t>(stream));
+    hipStream_t stream = r.stream;
     ExtT ext[EX_COUNT];
     ext[EX_PARAM] = {param, 1};
-    // encode once: x -> z0                                    (train_stage2_ns2d.py:144)
-    ext[EX_IN] = {x, xper};
-    ext[EX_OUT] = {zbuf[0], zper};
-    if ((rc = r.run(*pe, ext, arena))) return rc;
-    ExtT zcur = {zbuf[0], zper};
-    for (int t = 0; t < T; ++t) {   // strictly sequential in t  (train_stage2_ns2d.py:147-156)
+    int pong = (zcur.ptr == zbuf[0]) ? 1 : 0;
+    for (int t = 0; t < T; ++t) {   // strictly sequential in t, independent in b
         ExtT znext;
         if (latents_out) znext = {latents_out + (long)t * zper, (long)T * zper};
         else if (!to_x) znext = {out + (long)t * zper, (long)T * zper};
-        else znext = {zbuf[(t + 1) & 1], zper};
+        else { znext = {zbuf[pong], zper}; pong ^= 1; }
         ext[EX_IN] = zcur;
         ext[EX_OUT] = znext;
         if ((rc = r.run(*pp, ext, arena))) return rc;
@@ -979,10 +970,50 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
             if ((rc = r.run(*pd, ext, arena))) return rc;
         } else if (latents_out) {
             HIPCHK(e, hipMemcpy2DAsync(out + (long)t * zper, (size_t)T * zper * 4, znext.ptr, (size_t)T * zper * 4,
-                                       (size_t)zper * 4, B, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+                                       (size_t)zper * 4, B, hipMemcpyDeviceToDevice, stream));
         }
         zcur = znext;
     }
+    if (z_last)
+        HIPCHK(e, hipMemcpy2DAsync(z_last, (size_t)zper * 4, zcur.ptr, (size_t)zcur.bs * 4, (size_t)zper * 4, B,
+                                   hipMemcpyDeviceToDevice, stream));
+    return LNS_OK;
+}
+
+int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T, int to_x, float* out,
+                float* latents_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!e || !x || !out || B <= 0 || T <= 0) return LNS_EINVAL;
+    if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
+    if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    WsLayout L; int rc;
+    if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
+    Plan* pe;
+    if ((rc = get_plan(e, PK_ENC, B, 0, 0, &pe))) return rc;
+    const lns_config& c = e->cfg;
+    const long zper = (long)e->lat_C * e->lat_H * e->lat_W;
+    char* base = static_cast<char*>(ws);
+    Runner r(e, static_cast<hipStream_t>(stream));
+    ExtT ext[EX_COUNT];
+    ext[EX_PARAM] = {param, 1};
+    // encode once: x -> z0                                    (train_stage2_ns2d.py:144)
+    ext[EX_IN] = {x, (long)c.in_channels * c.Ly * c.Lx};
+    ext[EX_OUT] = {base, zper};
+    if ((rc = r.run(*pe, ext, base + L.arena_off))) return rc;
+    ExtT z0 = {base, zper};
+    if ((rc = rollout_loop(e, r, z0, param, B, T, to_x, out, latents_out, nullptr, L, base))) return rc;
+    return r.finish();
+}
+
+int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int B, int T, int to_x, float* out,
+                       float* z_last, void* ws, size_t ws_bytes, void* stream) {
+    if (!e || !z_in || !out || B <= 0 || T <= 0) return LNS_EINVAL;
+    if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
+    if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    WsLayout L; int rc;
+    if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
+    Runner r(e, static_cast<hipStream_t>(stream));
+    ExtT z0 = {z_in, (long)e->lat_C * e->lat_H * e->lat_W};
+    if ((rc = rollout_loop(e, r, z0, param, B, T, to_x, out, nullptr, z_last, L, static_cast<char*>(ws)))) return rc;
     return r.finish();
 }
 
@@ -1071,7 +1102,7 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     OPCHK(launch_conv(g.variant, a, s));
     OPCHK(hipStreamSynchronize(s));
-    hipFree(dw); hipFree(dmaps);
+    (void)hipFree(dw); (void)hipFree(dmaps);
     return LNS_OK;
 }
 
@@ -1089,7 +1120,7 @@ int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     OPCHK(launch_gn_stats(a, s));
     OPCHK(hipStreamSynchronize(s));
-    hipFree(dgb);
+    (void)hipFree(dgb);
     return LNS_OK;
 }
 

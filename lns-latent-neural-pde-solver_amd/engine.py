@@ -248,6 +248,26 @@ class Engine:
                                         ws.numel(), self._stream()), "lns_rollout")
         return (out, lat) if return_latents else out
 
+    def rollout_latent(self, z, steps, param=None, to_x=True, out=None):
+        """Continue from latent z: returns (out [B,steps,...], z after the last step)."""
+        import torch
+        z = self._dev(z)
+        B = z.shape[0]
+        c = self.cfg
+        C, H, W = self.latent_shape()
+        shape = (B, steps, c.in_channels, c.Ly, c.Lx) if to_x else (B, steps, C, H, W)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=z.device)
+        elif tuple(out.shape) != shape or not out.is_contiguous():
+            raise LnsError("preallocated output must be contiguous with shape %s" % (shape,))
+        z_last = torch.empty_like(z)
+        p = self._dev(param.to(torch.float32)) if param is not None else None
+        ws = self._workspace(B, z.device)
+        self._check(self._L.lns_rollout_latent(self._h, z.data_ptr(), p.data_ptr() if p is not None else None, B,
+                                               int(steps), int(bool(to_x)), out.data_ptr(), z_last.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), self._stream()), "lns_rollout_latent")
+        return out, z_last
+
     # -- diagnostics ----------------------------------------------------------------
     def trace_enable(self, on=True):
         self._check(self._L.lns_trace_enable(self._h, int(on)), "lns_trace_enable")

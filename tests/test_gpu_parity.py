@@ -1,0 +1,192 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against
+(a) the CPU oracle on seeded inputs, (b) the committed golden fixtures generated
+from the real reference, (c) size-independent properties at full bench size.
+
+Tolerances (fp32; north star: decoded fields within 1e-4 rel-L2 of the reference):
+  single kernel / single stage  2e-6 .. 2e-5   (fp32 accumulation-order noise)
+  rollout, T <= 64               1e-4
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from helpers import load_golden, rel_l2, case_args, case_inputs  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_TOL = 2e-6
+STAGE_TOL = 2e-5
+ROLLOUT_TOL = 1e-4
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_native_library_is_loaded():
+    _need_gpu()
+    from lns_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "liblns_hip.so" in maps
+
+
+def _conv_cases():
+    import gpu_checks as gc
+    return list(enumerate(gc.CONV_CASES))
+
+
+@pytest.mark.parametrize("idx,case", _conv_cases())
+def test_conv_kernel(idx, case):
+    _need_gpu()
+    import gpu_checks as gc
+    err, _ = gc.conv_case(seed=idx, **case)
+    assert err < KERNEL_TOL, (case, err)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, C=64, HW=1024, groups=32, eps=1e-6), dict(B=2, C=128, HW=256, groups=1, eps=1e-5),
+    dict(B=3, C=64, HW=4097, groups=8, eps=1e-5), dict(B=2, C=128, HW=105, groups=1, eps=1e-5, premul=True),
+    dict(B=2, C=64, HW=16384, groups=8, eps=1e-5)])
+def test_groupnorm_stats_kernel(case):
+    _need_gpu()
+    import gpu_checks as gc
+    assert gc.gn_case(**case) < KERNEL_TOL
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, heads=8, D=64, n=256), dict(B=2, heads=8, D=64, n=105), dict(B=2, heads=2, D=32, n=16),
+    dict(B=1, heads=8, D=64, n=288)])
+def test_attention_kernel(case):
+    _need_gpu()
+    import gpu_checks as gc
+    assert gc.attention_case(**case) < KERNEL_TOL
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, heads=8, C=64, H=64, W=64), dict(B=2, heads=8, C=64, H=32, W=32),
+    dict(B=1, heads=8, C=64, H=24, W=48), dict(B=1, heads=8, C=64, H=48, W=96),
+    dict(B=2, heads=2, C=32, H=16, W=16), dict(B=2, heads=2, C=32, H=8, W=8),
+    dict(B=2, heads=8, C=64, H=64, W=64, instnorm=False)])
+def test_fa_sandwich_kernel(case):
+    _need_gpu()
+    import gpu_checks as gc
+    assert gc.sandwich_case(**case) < KERNEL_TOL
+
+
+@pytest.mark.parametrize("preset", ["ns2d_mini", "ns2d_128"])
+def test_every_layer_matches_oracle(preset):
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    args = config.preset(preset)
+    x = filler.normal("x", (2, args.in_channels, args.Ly, args.Lx), 7)
+    rows = gc.layer_trace_compare(args, 1, x)
+    assert len(rows) > 20
+    bad = [r for r in rows if not (r[2] < STAGE_TOL)]
+    assert not bad, bad
+
+
+GOLDEN_CASES = ["ns2d_mini", "ns2d_mini_zeros", "ns2d_mini_sa", "ns2d_mini_nocoarse", "ns2d_64", "ns2d_128"]
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_rollout_matches_reference_golden(case):
+    """HIP rollout vs the REAL reference's outputs (fixtures from tools/make_golden.py)."""
+    _need_gpu()
+    import gpu_checks as gc
+    meta, g = load_golden(case)
+    args = case_args(meta)
+    model, _ = gc.build_models(args, meta["weight_seed"])
+    x, param = case_inputs(meta, args)
+    xd = torch.from_numpy(x).cuda()
+    T = meta["T"]
+    extra = (torch.from_numpy(param).cuda(),) if param is not None else ()
+    dec, lat = model.predict(xd, T, *extra, to_x=True, return_latents=True)
+    torch.cuda.synchronize()
+    dec, lat = dec.cpu().numpy(), lat.cpu().numpy()
+    assert dec.shape == (meta["B"], T, args.in_channels, args.Ly, args.Lx)
+    sub = meta["sub"]
+    report = []
+    for i, s in enumerate(meta["steps"]):
+        e_lat = rel_l2(lat[:, s - 1], g["lat"][:, i])
+        e_dec = rel_l2(dec[:, s - 1][..., ::sub, ::sub], g["dec"][:, i])
+        e64 = rel_l2(dec[:, s - 1][..., ::sub, ::sub], g["dec_f64"][:, i])
+        report.append((s, e_lat, e_dec, e64, float(g["ref_self_err"][s - 1])))
+        assert e_dec < ROLLOUT_TOL and e_lat < ROLLOUT_TOL, report
+    print(case, report)
+    nrm = np.sqrt((dec.astype(np.float64) ** 2).sum((-1, -2)))
+    np.testing.assert_allclose(nrm, g["dec_norm"], rtol=5e-4)
+    # to_x=False returns exactly the latents of the same rollout
+    lat2 = model.predict(xd, T, *extra, to_x=False).cpu().numpy()
+    assert np.array_equal(lat2, lat)
+
+
+def test_batch_shard_equivalence_and_b1():
+    """Trajectories are independent: a sample's result must not depend on the batch it
+    rides in (this is what makes trajectory sharding over GPUs collective-free), and B=1
+    works (the reference's squeeze() bug, SURVEY.md F9, is not reproduced)."""
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    args = config.preset("ns2d_64")
+    model, _ = gc.build_models(args, 3)
+    x = torch.from_numpy(filler.normal("xb", (5, args.in_channels, args.Ly, args.Lx), 11)).cuda()
+    full = model.predict(x, 3, to_x=True).cpu().numpy()
+    part = model.predict(x[1:3].contiguous(), 3, to_x=True).cpu().numpy()
+    one = model.predict(x[4:5].contiguous(), 3, to_x=True).cpu().numpy()
+    assert np.array_equal(full[1:3], part)
+    assert np.array_equal(full[4:5], one)
+
+
+def test_module_api_surface():
+    """encode / decode / forward / SimpleCNN.forward / rollout_latent compose to predict."""
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    args = config.preset("ns2d_mini")
+    model, orc = gc.build_models(args, 1)
+    x = torch.from_numpy(filler.normal("x", (3, args.in_channels, args.Ly, args.Lx), 7)).cuda()
+    z = model.x_to_z(x)
+    z1 = model.propagator(z)
+    y1 = model.z_to_x(z1)
+    full = model.predict(x, 2, to_x=True)
+    assert torch.equal(full[:, 0], y1)
+    eng = model._engine(x)
+    out, zl = eng.rollout_latent(z, 2, to_x=True)
+    assert torch.equal(out, full)
+    assert torch.equal(zl, model.propagator(z1))
+    assert rel_l2(model.vq_ae(x).cpu().numpy(), orc.z_to_x(orc.x_to_z(x.cpu().numpy()))) < STAGE_TOL
+    # standalone autoencoder / propagator objects with their own engines
+    from lns_amd.modules.autoencoder2d import SimpleAutoencoder
+    from lns_amd.train_stage2_ns2d import SimpleCNN
+    ae = SimpleAutoencoder(args)
+    ae.load_state_dict(model.vq_ae.state_dict())
+    assert torch.equal(ae.cuda().encode(x), z)
+    cnn = SimpleCNN(args.latent_dim, args.prop_n_block, args.prop_n_embd, args.dilation)
+    cnn.load_state_dict(model.propagator.state_dict())
+    assert torch.equal(cnn.cuda()(z), z1)
+    # weights changed after the first call are picked up
+    with torch.no_grad():
+        getattr(model.propagator.out_proj, "1").bias.add_(1.0)
+    assert not torch.equal(model.propagator(z), z1)
+
+
+def test_full_size_rollout_properties():
+    """BASELINE config 2 shape (B=64, T=64 is the bench; here T=4 to bound memory/time):
+    finite, per-sample independent (bitwise) and close to the oracle on a sub-batch."""
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    args = config.preset("ns2d_128")
+    model, orc = gc.build_models(args, 1)
+    x = filler.normal("xfull", (64, args.in_channels, args.Ly, args.Lx), 5)
+    xd = torch.from_numpy(x).cuda()
+    y = model.predict(xd, 4, to_x=True)
+    assert torch.isfinite(y).all()
+    sub = model.predict(xd[10:12].contiguous(), 4, to_x=True)
+    assert torch.equal(y[10:12], sub)
+    ref = orc.predict(x[10:12], 4, to_x=True)
+    assert rel_l2(sub.cpu().numpy(), ref) < STAGE_TOL * 2

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <type_traits>
@@ -95,10 +96,10 @@ static void pack_conv_weight(float* dst, const float* src, int cout_off, int cou
                 dst[((size_t)t * Cin_pad + ci) * Cout_pad + cout_off + co] = src[((size_t)co * cin + ci) * taps + t];
 }
 
-struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Hout, Wout; };
+struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Hout, Wout, kc_log2; };
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
-                          int kc_log2, int Cout_pad, int force_variant) {
+                          int kc_log2_pack, int Cout_pad, int force_variant) {
     g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
     g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
     if (g.Hout <= 0 || g.Wout <= 0) return false;
@@ -106,35 +107,49 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
     if (force_variant >= 0) cands = {force_variant};
     else if (Cout <= 32) cands = {CV_S32};
     else if (Cout <= 64) cands = {CV_L64, CV_M64, CV_S64};
+    else if (getenv("LNS_CONV_NO_128")) cands = {CV_L64, CV_M64, CV_S64};   // tuning knob (tile choice only)
     else cands = {CV_L128, CV_M128, CV_S64};
+    g.kc_log2 = conv_pick_kc_log2(k, stride, kc_log2_pack);
     static const int pref[] = {5, 6, 4, 7, 3, 8};   // log2 BW preference on ties: 32,64,16,128,8,256
     bool found = false;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         const ConvVariantInfo vi = conv_variant_info(cands[ci]);
         if (Cout_pad % vi.TM != 0) continue;
-        long best_cost = -1; int best_bw = -1;
-        for (int pi = 0; pi < 6; ++pi) {
-            const int lb = pref[pi];
-            const int BW = 1 << lb;
-            if (BW > vi.TN) continue;
-            const int BH = vi.TN / BW;
-            const long cost = (long)((g.Hout + BH - 1) / BH) * BH * ((g.Wout + BW - 1) / BW) * BW;
-            ConvArgs tmp;
-            memset(&tmp, 0, sizeof tmp);
-            tmp.kc_log2 = kc_log2; tmp.ks = k;
+        ConvArgs tmp;
+        memset(&tmp, 0, sizeof tmp);
+        tmp.ks = k; tmp.kc_log2 = g.kc_log2; tmp.Cin_pad = 1 << kc_log2_pack;
+        int best_bw = -1, txn = 0, tyn = 0;
+        if (k == 1) {
+            // 1x1: the image is a flat array of H*W pixels, a tile is TN consecutive pixels
+            if (stride != 1 || pad[0] || pad[1] || pad[2] || pad[3]) return false;
+            tmp.PH = 1; tmp.PW = 1;
+            if (!conv_fits(cands[ci], tmp)) continue;
+            best_bw = 0;
+            while ((1 << best_bw) < vi.TN) ++best_bw;
+            txn = (g.Hout * g.Wout + vi.TN - 1) / vi.TN; tyn = 1;
+        } else {
+            long best_cost = -1;
+            for (int pi = 0; pi < 6; ++pi) {
+                const int lb = pref[pi];
+                const int BW = 1 << lb;
+                if (BW > vi.TN) continue;
+                const int BH = vi.TN / BW;
+                const long cost = (long)((g.Hout + BH - 1) / BH) * BH * ((g.Wout + BW - 1) / BW) * BW;
+                tmp.PH = (BH - 1) * stride + (k - 1) * dil + 1;
+                tmp.PW = (BW - 1) * stride + (k - 1) * dil + 1;
+                if (!conv_fits(cands[ci], tmp)) continue;
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bw = lb; }
+            }
+            if (best_bw < 0) continue;
+            const int BW = 1 << best_bw, BH = vi.TN / BW;
+            txn = (g.Wout + BW - 1) / BW; tyn = (g.Hout + BH - 1) / BH;
             tmp.PH = (BH - 1) * stride + (k - 1) * dil + 1;
             tmp.PW = (BW - 1) * stride + (k - 1) * dil + 1;
-            if (conv_lds_bytes(cands[ci], tmp) > 150 * 1024) continue;
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bw = lb; }
         }
-        if (best_bw < 0) continue;
-        const int BW = 1 << best_bw, BH = vi.TN / BW;
-        const int txn = (g.Wout + BW - 1) / BW, tyn = (g.Hout + BH - 1) / BH;
         const long blocks = (long)B * txn * tyn * ((Cout + vi.TM - 1) / vi.TM);
         g.variant = cands[ci]; g.bw_log2 = best_bw; g.tiles_x = txn; g.tiles_y = tyn;
         g.cout_tiles = (Cout + vi.TM - 1) / vi.TM;
-        g.PH = (BH - 1) * stride + (k - 1) * dil + 1;
-        g.PW = (BW - 1) * stride + (k - 1) * dil + 1;
+        g.PH = tmp.PH; g.PW = tmp.PW;
         found = true;
         if (blocks >= 512) break;
     }
@@ -280,8 +295,10 @@ struct Planner {
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
         std::vector<int> rm, cm;
-        build_axis_map(rm, (g.tiles_y - 1) * BH * stride + g.PH, in.H, Hv, in.sch, pad[0], pad[1], my);
-        build_axis_map(cm, (g.tiles_x - 1) * BW * stride + g.PW, in.W, Wv, in.scw, pad[2], pad[3], mx);
+        if (k == 3) {
+            build_axis_map(rm, (g.tiles_y - 1) * BH * stride + g.PH, in.H, Hv, in.sch, pad[0], pad[1], my);
+            build_axis_map(cm, (g.tiles_x - 1) * BW * stride + g.PW, in.W, Wv, in.scw, pad[2], pad[3], mx);
+        } else if (in.vH) throw std::runtime_error("1x1 conv of a resized tensor is not supported: " + name);
         TRef out;
         if (out_forced) out = *out_forced;
         else out = alloc_t(pk.cout, g.Hout, g.Wout);
@@ -299,15 +316,20 @@ struct Planner {
         a.bias = pk.has_bias ? as_ptr<const float>(wt(pk.b_off)) : nullptr;
         a.ss = as_ptr<const float>(in.ss);
         a.act_in = in.act; a.act_out = act_out;
-        a.rowmap = as_ptr<const int>(const_ints(rm));
-        a.colmap = as_ptr<const int>(const_ints(cm));
+        if (k == 3) {
+            a.rowmap = as_ptr<const int>(const_ints(rm));
+            a.colmap = as_ptr<const int>(const_ints(cm));
+        }
+        // 16-byte patch loads: every channel row of every sample must start 16-byte aligned
+        a.vec4 = (k == 1 && ((in.H * in.W) % 4 == 0)) ? 1 : 0;
         a.y = as_ptr<float>(out.ptr); a.y_bs = out.bs; a.Cout = pk.cout; a.Hout = g.Hout; a.Wout = g.Wout;
         if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
-        a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = pk.kc_log2;
+        a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.kc_log2;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
+        a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
         op.flops = 2.0 * B * g.Hout * g.Wout * (double)pk.cout * pk.cin * k * k;
         op.bytes = 4.0 * B * ((double)in.C * in.H * in.W + (double)pk.cout * g.Hout * g.Wout * (res ? 2 : 1));
         plan->ops.push_back(op);
@@ -759,15 +781,22 @@ struct Runner {
     int finish() {
         if (!e->timing_on || evs.empty()) return LNS_OK;
         HIPCHK(e, hipStreamSynchronize(stream));
-        if (e->timing.empty()) {
+        static const bool by_name = getenv("LNS_TIMING_BY_NAME") != nullptr;   // per-layer breakdown for profiling
+        if (e->timing.empty() && !by_name) {
             e->timing.resize(CLS_COUNT);
             for (int i = 0; i < CLS_COUNT; ++i) e->timing[i].name = kClsName[i];
         }
         for (EvPair& ev : evs) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, ev.a, ev.b);
-            TimeRec& t = e->timing[ev.cls];
-            t.ms += ms; t.launches += 1; t.flops += ev.op->flops; t.bytes += ev.op->bytes;
+            TimeRec* t = nullptr;
+            if (!by_name) t = &e->timing[ev.cls];
+            else {
+                const std::string nm = std::string(kClsName[ev.cls]) + ":" + ev.op->name;
+                for (TimeRec& r : e->timing) if (r.name == nm) { t = &r; break; }
+                if (!t) { e->timing.emplace_back(); t = &e->timing.back(); t->name = nm; }
+            }
+            t->ms += ms; t->launches += 1; t->flops += ev.op->flops; t->bytes += ev.op->bytes;
             (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
         }
         evs.clear();
@@ -1057,6 +1086,7 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
                   int pad_r, int mode_y, int mode_x, const float* ss, int act_in, int act_out, const float* residual,
                   const float* badd, float* y, int tile_variant, void* stream) {
     if (!x || !w_host || !y || (ksize != 1 && ksize != 3)) return LNS_EINVAL;
+    if (act_in != ACT_NONE && act_in != ACT_SWISH) return LNS_EINVAL;   // prologue: GroupNorm scale/shift + Swish only
     OPCHK(init_kernels());
     ConvPack pk;
     pk.cin = Cin; pk.cout = Cout; pk.k = ksize;
@@ -1094,11 +1124,13 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     a.x = x; a.x_bs = (long)Cin * Hin * Win; a.Cin = Cin; a.Hin = Hin; a.Win = Win;
     a.w = dw; a.bias = bias_host ? dw + wcount : nullptr; a.ss = ss; a.act_in = act_in; a.act_out = act_out;
     a.rowmap = dmaps; a.colmap = dmaps + rm.size();
+    a.vec4 = (ksize == 1 && ((Hin * Win) % 4 == 0)) ? 1 : 0;
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
-    a.kc_log2 = pk.kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
+    a.kc_log2 = g.kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
+    a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
     hipStream_t s = static_cast<hipStream_t>(stream);
     OPCHK(launch_conv(g.variant, a, s));
     OPCHK(hipStreamSynchronize(s));

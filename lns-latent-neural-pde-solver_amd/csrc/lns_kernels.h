@@ -34,6 +34,8 @@ struct ConvArgs {
     int tiles_x, tiles_y, cout_tiles;
     int bw_log2;           // pixel tile width = 1<<bw_log2, height = TN>>bw_log2
     int PH, PW;            // staged patch extent
+    unsigned ph_magic;     // ceil(2^32 / PH), 0 when PH == 1
+    int vec4;              // 1x1 only: 16-byte patch loads (HW % 4 == 0, 16-byte aligned bases)
     int B;
 };
 
@@ -42,6 +44,8 @@ enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4,
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
 size_t conv_lds_bytes(int variant, const ConvArgs& a);
+int conv_pick_kc_log2(int ks, int stride, int kc_log2_max);
+bool conv_fits(int variant, const ConvArgs& a);
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------

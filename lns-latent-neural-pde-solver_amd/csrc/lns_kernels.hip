@@ -44,30 +44,43 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 //   - weights are the MFMA A operand (rows = couts), activations the B operand
 //     (cols = pixels): output rows land in registers, output pixels on lanes, so
 //     every store instruction writes 128-byte contiguous NCHW row segments;
-//   - per K stage (KC input channels): the haloed input patch is staged in LDS
-//     with the producer's GroupNorm scale/shift + activation applied on the fly
-//     (padding / circular wrap / nearest-upsample resolved through row/col
-//     index maps, never materialised), next to the [tap][k][cout] weight slab;
-//   - K order inside a stage: tap-major, channel pairs (k = 2*kk + kh).
+//   - per K stage (KC input channels) the input patch is staged in LDS with the
+//     producer's GroupNorm scale/shift + Swish applied on the fly.  3x3: haloed
+//     patch, padding / circular wrap / nearest-upsample resolved through row/col
+//     index maps (never materialised).  1x1: the image is a flat pixel array, a
+//     stage is KC contiguous pixel runs, loaded 16 B per lane when HW % 4 == 0;
+//   - software pipeline: while the MFMAs of stage c run out of LDS buffer c&1 the
+//     global loads of stage c+1 (patch + weight slab) are in flight into
+//     registers; they are transformed and written to the other buffer afterwards
+//     -> ONE barrier per stage, global latency hidden behind MFMA;
+//   - K order: stage-major (KC fixed per kernel size, see conv_pick_kc_log2),
+//     tap-major inside a stage, channel pairs (k = 2*kk + kh).
 // ===========================================================================
-struct __attribute__((aligned(16))) RowEnt { int off; float s; float t; int pad; };
+#define CONV_MAXE3 9    // 3x3: scalar patch elements per thread per stage
+#define CONV_MAXE1 16   // 1x1: floats per thread per stage (4 x float4 when vectorised)
+#define CONV_MAXW 5     // weight float4 per thread per stage
 
-template <int MT, int NT, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(ConvArgs a) {
+__device__ __forceinline__ float swish_f(float v) { return v / (1.0f + expf(-v)); }
+
+template <int MT, int NT, int WGM, int WGN, int KS, bool VEC>
+__global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int TM = WGM * MT * 32;
     constexpr int TN = WGN * NT * 32;
+    constexpr int V4 = TM / 4;
+    constexpr int MAXE = KS == 3 ? CONV_MAXE3 : CONV_MAXE1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int KC = 1 << a.kc_log2;
     const int PH = a.PH, PW = a.PW;
-    const int PLANE = PH * PW;
-    const int taps = a.ks * a.ks;
+    const int PLANE = KS == 3 ? PH * PW : TN;
     const int xs_floats = (KC * PLANE + 3) & ~3;
-    float* Xs = reinterpret_cast<float*>(smem);
-    float* Ws = Xs + xs_floats;
-    RowEnt* rowtab = reinterpret_cast<RowEnt*>(Ws + taps * KC * TM);
-    int* coltab = reinterpret_cast<int*>(rowtab + KC * PH);
+    const int ws_floats = KS * KS * KC * TM;
+    const int buf_floats = xs_floats + ws_floats;
+    float* lds = reinterpret_cast<float*>(smem);           // 2 x [Xs | Ws]
+    float* ssl = lds + 2 * buf_floats;                     // [Cin_pad][2] scale/shift of this sample
+    int* rmap = reinterpret_cast<int*>(ssl + a.Cin_pad * 2);
+    int* cmap = rmap + PH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -84,14 +97,67 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(ConvArgs a) {
     const int BH = TN >> a.bw_log2;
     const int HWin = a.Hin * a.Win;
     const float* xb = a.x + (long)b * a.x_bs;
+    const bool has_ss = a.ss != nullptr;
+    const bool has_act = a.act_in == ACT_SWISH;
 
-    for (int px = tid; px < PW; px += NTHR) coltab[px] = a.colmap[tx * BW * a.stride + px];
+    if (has_ss)
+        for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
+            ssl[i] = (i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : 0.0f;
+    if (KS == 3) {
+        for (int i = tid; i < PH; i += NTHR) rmap[i] = a.rowmap[ty * BH * a.stride + i];
+        for (int i = tid; i < PW; i += NTHR) cmap[i] = a.colmap[tx * BW * a.stride + i];
+    }
+    __syncthreads();
+
+    // ---- per-thread patch descriptors (the same in every stage) ----------------
+    // 3x3   : source offset inside a stage (-1 = zero) | channel-in-stage << 24, one per element
+    // 1x1   : one descriptor per 4 consecutive pixels (VEC) or per pixel
+    constexpr int NDESC = KS == 3 ? CONV_MAXE3 : (VEC ? CONV_MAXE1 / 4 : CONV_MAXE1);
+    int pdesc[NDESC];
+    const int p0 = tx * TN;   // 1x1: first flat pixel of this tile
+    if (KS == 3) {
+        const int total = KC * PLANE;
+        int r = tid / PW, cx = tid - r * PW;                 // r = cl*PH + py
+        const int r_step = NTHR / PW, c_step = NTHR - r_step * PW;
+#pragma unroll
+        for (int j = 0; j < NDESC; ++j) {
+            int d = -1;
+            if (tid + j * NTHR < total) {
+                const int cl = a.ph_magic ? (int)__umulhi((unsigned)r, a.ph_magic) : r;   // r / PH
+                const int py = r - cl * PH;
+                const int sy = rmap[py];
+                const int sx = cmap[cx];
+                if (sy >= 0 && sx >= 0) d = (cl * HWin + sy * a.Win + sx) | (cl << 24);
+            }
+            pdesc[j] = d;
+            cx += c_step; r += r_step;
+            if (cx >= PW) { cx -= PW; ++r; }
+        }
+    } else {
+        constexpr int PER = VEC ? TN / 4 : TN;               // descriptors per channel
+#pragma unroll
+        for (int j = 0; j < NDESC; ++j) {
+            const int idx = tid + j * NTHR;
+            const int cl = idx / PER, pp = (idx - cl * PER) * (VEC ? 4 : 1);
+            pdesc[j] = (cl < KC && p0 + pp < HWin) ? ((cl * HWin + p0 + pp) | (cl << 24)) : -1;
+        }
+    }
+    // per-thread weight slab descriptors (float offset of the stage-0 source)
+    const int nw4 = KS * KS * KC * V4;
+    int wdesc[CONV_MAXW];
+#pragma unroll
+    for (int i = 0; i < CONV_MAXW; ++i) {
+        const int fi = tid + i * NTHR;
+        const int row = fi / V4, c4 = fi - row * V4;
+        const int tap = row >> a.kc_log2, k = row & (KC - 1);
+        wdesc[i] = (fi < nw4) ? ((tap * a.Cin_pad + k) * a.Cout_pad + ct * TM + c4 * 4) : -1;
+    }
 
     int boff[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
-        boff[nt] = ((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride;
+        boff[nt] = KS == 3 ? ((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride : p;
     }
 
     f32x16 acc[MT][NT];
@@ -102,106 +168,162 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    // flat staging index -> (row, col) of the patch, advanced incrementally
-    const int r_start = tid / PW, c_start = tid - r_start * PW;
-    const int r_step = NTHR / PW, c_step = NTHR - r_step * PW;
-    const int rowbase = ty * BH * a.stride;
+    float pv[MAXE];
+    float wv[CONV_MAXW][4];
 
+    auto issue_loads = [&](int c0) __attribute__((always_inline)) {
+        const float* xc = xb + (long)c0 * HWin;
+#pragma unroll
+        for (int j = 0; j < NDESC; ++j) {
+            const int d = pdesc[j];
+            const bool ok = d >= 0 && (c0 + (d >> 24)) < a.Cin;
+            // loads are unconditional (no branches); masked elements read the sample's first
+            // floats instead (always in bounds, 16-byte aligned) and are zeroed by the select
+            const float* src = ok ? xc + (d & 0xFFFFFF) : xb;
+            if (KS == 1 && VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                pv[4 * j + 0] = ok ? t.x : 0.0f; pv[4 * j + 1] = ok ? t.y : 0.0f;
+                pv[4 * j + 2] = ok ? t.z : 0.0f; pv[4 * j + 3] = ok ? t.w : 0.0f;
+            } else {
+                const float t = *src;
+                pv[j] = ok ? t : 0.0f;
+            }
+        }
+        const float* wc = a.w + (long)c0 * a.Cout_pad;
+#pragma unroll
+        for (int i = 0; i < CONV_MAXW; ++i) {
+            if (KS == 1 && i >= 2) break;                   // 1x1: at most 16*128/4/256 = 2 float4
+            const float4 t = *reinterpret_cast<const float4*>(wc + (wdesc[i] < 0 ? 0 : wdesc[i]));
+            wv[i][0] = t.x; wv[i][1] = t.y; wv[i][2] = t.z; wv[i][3] = t.w;
+        }
+    };
+    auto xform = [&](float v, int c) __attribute__((always_inline)) -> float {
+        if (has_ss) v = v * ssl[2 * c] + ssl[2 * c + 1];
+        if (has_act) v = swish_f(v);
+        return v;
+    };
+    auto write_lds = [&](int c0, float* Xs, float* Ws) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NDESC; ++j) {
+            const int d = pdesc[j];
+            const int c = c0 + (d >> 24);
+            const bool ok = d >= 0 && c < a.Cin;
+            if (KS == 1 && VEC) {
+                const int idx = tid + j * NTHR;
+                if (idx < KC * (TN / 4)) {
+                    float4 t = make_float4(pv[4 * j], pv[4 * j + 1], pv[4 * j + 2], pv[4 * j + 3]);
+                    if (ok && (has_ss || has_act)) { t.x = xform(t.x, c); t.y = xform(t.y, c); t.z = xform(t.z, c); t.w = xform(t.w, c); }
+                    *reinterpret_cast<float4*>(Xs + idx * 4) = t;
+                }
+            } else {
+                const int idx = tid + j * NTHR;
+                if (idx < KC * PLANE) {
+                    float v = pv[j];
+                    if (ok && (has_ss || has_act)) v = xform(v, c);
+                    Xs[idx] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CONV_MAXW; ++i) {
+            if (KS == 1 && i >= 2) break;
+            if (wdesc[i] >= 0)
+                *reinterpret_cast<float4*>(Ws + (tid + i * NTHR) * 4) = make_float4(wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
+        }
+    };
+
+    int toff[KS * KS];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) toff[t] = KS == 3 ? ((t / 3) * a.dil) * PW + (t % 3) * a.dil : 0;
+
+    issue_loads(0);
+    int buf = 0;
     for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
-        __syncthreads();   // previous stage fully consumed (also orders coltab on the first pass)
-        for (int r = tid; r < KC * PH; r += NTHR) {
-            const int cl = r / PH;
-            const int py = r - cl * PH;
-            const int c = c0 + cl;
-            const int sy = a.rowmap[rowbase + py];
-            RowEnt e;
-            e.off = -1; e.s = 1.0f; e.t = 0.0f; e.pad = 0;
-            if (c < a.Cin && sy >= 0) {
-                e.off = cl * HWin + sy * a.Win;
-                if (a.ss) {
-                    e.s = a.ss[((long)b * a.Cin + c) * 2];
-                    e.t = a.ss[((long)b * a.Cin + c) * 2 + 1];
-                }
-            }
-            rowtab[r] = e;
-        }
-        // weight slab: rows (tap, k) of TM contiguous couts
-        {
-            constexpr int V4 = TM / 4;
-            const int nrow = taps * KC;
-            for (int i = tid; i < nrow * V4; i += NTHR) {
-                const int row = i / V4, c4 = i - row * V4;
-                const int tap = row >> a.kc_log2, k = row & (KC - 1);
-                const float4 v = *reinterpret_cast<const float4*>(
-                    a.w + ((long)(tap * a.Cin_pad + c0 + k) * a.Cout_pad + ct * TM + c4 * 4));
-                *reinterpret_cast<float4*>(Ws + row * TM + c4 * 4) = v;
-            }
-        }
+        float* Xs = lds + buf * buf_floats;
+        float* Ws = Xs + xs_floats;
+        write_lds(c0, Xs, Ws);
         __syncthreads();
-        {
-            const float* xc = xb + (long)c0 * HWin;
-            int r = r_start, cx = c_start;
-            const int total = KC * PLANE;
-            for (int idx = tid; idx < total; idx += NTHR) {
-                const RowEnt e = rowtab[r];
-                const int sx = coltab[cx];
-                float v = 0.0f;
-                if (e.off >= 0 && sx >= 0) {
-                    v = xc[e.off + sx] * e.s + e.t;
-                    v = act_apply(v, a.act_in);
-                }
-                Xs[idx] = v;
-                r += r_step;
-                cx += c_step;
-                if (cx >= PW) { cx -= PW; ++r; }
-            }
-        }
-        __syncthreads();
+        if (c0 + KC < a.Cin_pad) issue_loads(c0 + KC);   // in flight during the MFMAs below
 
         const float* wbase = Ws + wm * (MT * 32) + l31 + kh * TM;
         const float* xbase = Xs + kh * PLANE;
-        for (int ky = 0; ky < a.ks; ++ky)
-            for (int kx = 0; kx < a.ks; ++kx) {
-                const float* wsp = wbase + (ky * a.ks + kx) * KC * TM;
-                const float* xsp = xbase + (ky * a.dil) * PW + kx * a.dil;
-#pragma unroll 4
-                for (int kk = 0; kk < KC / 2; ++kk) {
-                    float av[MT], bv[NT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) av[mt] = wsp[(2 * kk) * TM + mt * 32];
+        for (int t = 0; t < KS * KS; ++t) {
+            const float* wsp = wbase + t * KC * TM;
+            const float* xsp = xbase + toff[t];
+#pragma unroll 8
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                float av[MT], bv[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = xsp[(2 * kk) * PLANE + boff[nt]];
+                for (int mt = 0; mt < MT; ++mt) av[mt] = wsp[(2 * kk) * TM + mt * 32];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = xsp[(2 * kk) * PLANE + boff[nt]];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-                }
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
             }
+            // keep the scheduler from hoisting every tap's LDS reads to the top of the stage
+            // (register blow-up); one tap of look-ahead is plenty at 64 cycles per MFMA
+            if (KS == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        buf ^= 1;
     }
 
-    // epilogue
+    // ---- epilogue ---------------------------------------------------------------
     const int HWo = a.Hout * a.Wout;
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int p = (wn * NT + nt) * 32 + l31;
-        const int oy = ty * BH + (p >> a.bw_log2);
-        const int ox = tx * BW + (p & (BW - 1));
-        const bool pv = (oy < a.Hout) && (ox < a.Wout);
-        const long pix = (long)oy * a.Wout + ox;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
+        const int cob = ct * TM + (wm * MT + mt) * 32 + 4 * kh;
+        if (a.bias || a.badd) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = ct * TM + (wm * MT + mt) * 32 + drow(r, kh);
-                if (pv && co < a.Cout) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                float add = 0.0f;
+                if (co < a.Cout) {
+                    if (a.bias) add += a.bias[co];
+                    if (a.badd) add += a.badd[(long)b * a.Cout + co];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
+            }
+        }
+    }
+    if (a.act_out == ACT_GELU) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_apply(acc[mt][nt][r], ACT_GELU);
+    } else if (a.act_out == ACT_SWISH) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = (wn * NT + nt) * 32 + l31;
+        int oy, ox;
+        if (KS == 3) { oy = ty * BH + (p >> a.bw_log2); ox = tx * BW + (p & (BW - 1)); }
+        else { oy = 0; ox = p0 + p; }
+        const bool pvld = KS == 3 ? ((oy < a.Hout) && (ox < a.Wout)) : (ox < HWo);
+        const int pix = oy * a.Wout + ox;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int cob = ct * TM + (wm * MT + mt) * 32 + 4 * kh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                if (pvld && co < a.Cout) {
+                    const int o = co * HWo + pix;
                     float v = acc[mt][nt][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.badd) v += a.badd[(long)b * a.Cout + co];
-                    v = act_apply(v, a.act_out);
-                    const long o = (long)co * HWo + pix;
                     if (rb) v += rb[o];
                     yb[o] = v;
                 }
@@ -215,24 +337,45 @@ static const ConvVariantInfo kConvInfo[CV_COUNT] = {
 
 ConvVariantInfo conv_variant_info(int v) { return kConvInfo[v]; }
 
+// Stage depth (channels per LDS stage).  It is a function of the kernel size and stride ONLY
+// (3x3: 4, 3x3 stride 2: 2, 1x1: 16), never of the tile variant or batch: the fp32
+// accumulation order of an output element is then independent of how the launch was tiled,
+// so a trajectory's result is bit-identical whatever batch (or GPU shard) it is computed in.
+int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
+    int lg = ks == 3 ? (stride == 1 ? 2 : 1) : 4;
+    return lg < kc_log2_max ? lg : kc_log2_max;
+}
+
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
     const int KC = 1 << a.kc_log2;
-    const int TM = kConvInfo[variant].TM;
-    size_t xs = ((size_t)KC * a.PH * a.PW + 3) & ~(size_t)3;
+    const int TM = kConvInfo[variant].TM, TN = kConvInfo[variant].TN;
+    size_t xs = ((size_t)KC * (a.ks == 3 ? a.PH * a.PW : TN) + 3) & ~(size_t)3;
     size_t ws = (size_t)a.ks * a.ks * KC * TM;
-    return (xs + ws) * 4 + (size_t)KC * a.PH * sizeof(RowEnt) + (size_t)a.PW * 4 + 16;
+    return (2 * (xs + ws) + (size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
+}
+
+bool conv_fits(int variant, const ConvArgs& a) {
+    const long KC = 1 << a.kc_log2;
+    const int TM = kConvInfo[variant].TM, TN = kConvInfo[variant].TN;
+    if (conv_lds_bytes(variant, a) > 150 * 1024 || (a.Cin_pad % KC) != 0 || KC < 2) return false;
+    if ((long)a.ks * a.ks * KC * TM > (long)(a.ks == 3 ? CONV_MAXW : 2) * 1024) return false;
+    if (a.ks == 3) return KC * a.PH * a.PW <= (long)CONV_MAXE3 * 256;
+    return KC * TN <= (long)CONV_MAXE1 * 256;
 }
 
 template <int MT, int NT, int WGM, int WGN>
 static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, s, a);
+    dim3 blk(64 * WGM * WGN);
+    if (a.ks == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false>), grid, blk, lds, s, a);
+    else if (a.vec4) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, true>), grid, blk, lds, s, a);
+    else hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, false>), grid, blk, lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
+    if (!conv_fits(variant, a)) return hipErrorInvalidValue;
     const size_t lds = conv_lds_bytes(variant, a);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
     switch (variant) {
         case CV_L128: return launch_conv_t<2, 4, 2, 2>(a, lds, s);
         case CV_L64: return launch_conv_t<2, 2, 1, 4>(a, lds, s);
@@ -774,12 +917,24 @@ hipError_t init_kernels() {
 #define LNS_SET_LDS(k)                                                                            \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
-    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 3, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, false>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 3, false>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 1, true>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 1, false>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 3, false>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, true>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2>))
     LNS_SET_LDS((fa_sandwich_kernel<2, 2>))

@@ -105,7 +105,9 @@ CONV_CASES = [
     dict(B=2, Cin=64, Cout=64, H=16, W=16, k=3, up=(32, 32), mode=(1, 1)),
     dict(B=2, Cin=64, Cout=64, H=28, W=60, k=3, up=(61, 121), mode=(0, 0)),
     dict(B=2, Cin=64, Cout=128, H=32, W=32, k=3, ss=True, act_in=1, res=True),
-    dict(B=2, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act_in=2, act_out=2, badd=True),
+    dict(B=2, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act_in=1, act_out=2, badd=True),
+    dict(B=2, Cin=64, Cout=64, H=61, W=121, k=1, ss=True, act_in=1, res=True),
+    dict(B=2, Cin=128, Cout=64, H=30, W=60, k=1, bias=False),
     dict(B=3, Cin=64, Cout=2048, H=1, W=64, k=1, bias=False),
     dict(B=1, Cin=32, Cout=32, H=8, W=8, k=3, mode=(1, 1)),
 ]

@@ -771,10 +771,13 @@ hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s) {
 // 128-byte row-segment stores.  InstanceNorm (biased var) is computed from the
 // accumulator registers (two-pass, exact) and applied before the store.
 // ===========================================================================
-template <int HT, int WT>
+template <int HT, int WT, bool VEC>
 __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int planes_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HP = HT * 32 + 1, WP = WT * 32 + 1;
+    // plane prefetch registers: one 64-lane wave moves a whole (padded) plane
+    constexpr int NPF = (HT * 32) * (WT * 32) / 64;        // floats per lane
+    constexpr int NQ = VEC ? NPF / 4 : NPF;                // load instructions per lane
     float* Kxs = reinterpret_cast<float*>(smem);          // [HT*32][HP]
     float* Kys = Kxs + HT * 32 * HP;                      // [WT*32][WP]
     float* Pall = Kys + WT * 32 * WP;                     // 4 x [HT*32][WP]
@@ -793,23 +796,60 @@ __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int 
         Kys[r * WP + c] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
     }
     float* Ps = Pall + wave * (HT * 32 * WP);
-    const int c_begin = blockIdx.x * planes_per_block;
-    const int iters = (planes_per_block + 3) / 4;
-    const float inv_cnt = 1.0f / (float)(H * W);
-    for (int it_ = 0; it_ < iters; ++it_) {
-        const int cl = it_ * 4 + wave;
-        const int c = c_begin + cl;
-        const bool active = (cl < planes_per_block) && (c < C);
-        __syncthreads();   // Kxs/Kys ready (first pass); previous plane of every wave consumed
-        if (active) {
-            const float* pg = a.u + (((long)b * a.heads + h) * C + c) * H * W;
-            for (int i = lane; i < HT * 32 * (WT * 32); i += 64) {
-                const int r = i / (WT * 32), cc = i - r * (WT * 32);
-                Ps[r * WP + cc] = (r < H && cc < W) ? pg[(long)r * W + cc] : 0.0f;
+    for (int i = lane; i < HT * 32 * WP; i += 64) Ps[i] = 0.0f;   // padding stays zero for every plane
+    __syncthreads();
+
+    // per-lane source / LDS offsets of the plane elements this lane moves (same for every plane)
+    int soff[NQ], doff[NQ];
+    {
+        const int per_row = VEC ? W / 4 : W;
+        const int nvalid = H * per_row;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int f = lane + 64 * q;
+            const int r = f / per_row, c = (f - r * per_row) * (VEC ? 4 : 1);
+            soff[q] = f < nvalid ? r * W + c : -1;
+            doff[q] = r * WP + c;
+        }
+    }
+    float pf[NPF];
+    auto prefetch = [&](const float* pg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int so = soff[q] < 0 ? 0 : soff[q];      // unconditional, clamped
+            if (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(pg + so);
+                pf[4 * q] = t.x; pf[4 * q + 1] = t.y; pf[4 * q + 2] = t.z; pf[4 * q + 3] = t.w;
+            } else {
+                pf[q] = pg[so];
             }
         }
-        __syncthreads();
-        if (!active) continue;
+    };
+
+    const int c_begin = blockIdx.x * planes_per_block;
+    const float inv_cnt = 1.0f / (float)(H * W);
+    const long plane0 = ((long)b * a.heads + h) * C;
+    int c = c_begin + wave;
+    const int c_end = min(c_begin + planes_per_block, C);
+    if (c < c_end) prefetch(a.u + (plane0 + c) * H * W);
+    for (; c < c_end; c += 4) {
+        // registers -> this wave's private LDS plane (row-major, odd row stride: the column
+        // reads of the first product are bank-conflict free).  No block barrier: LDS
+        // operations of one wave execute in order.
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (soff[q] >= 0) {
+                if (VEC) {
+                    Ps[doff[q]] = pf[4 * q]; Ps[doff[q] + 1] = pf[4 * q + 1];
+                    Ps[doff[q] + 2] = pf[4 * q + 2]; Ps[doff[q] + 3] = pf[4 * q + 3];
+                } else {
+                    Ps[doff[q]] = pf[q];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (c + 4 < c_end) prefetch(a.u + (plane0 + c + 4) * H * W);   // in flight during the MFMAs
+
         f32x16 Y[HT][WT];
 #pragma unroll
         for (int i = 0; i < HT; ++i)
@@ -869,7 +909,7 @@ __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int 
                     }
             rstd = 1.0f / sqrtf(wave_sum(q) * inv_cnt + a.eps);
         }
-        float* og = a.out + (((long)b * a.heads + h) * C + c) * H * W;
+        float* og = a.out + (plane0 + c) * H * W;
 #pragma unroll
         for (int it = 0; it < HT; ++it)
 #pragma unroll
@@ -877,8 +917,9 @@ __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = it * 32 + drow(r, kh), l = lt * 32 + l31;
-                    if (i < H && l < W) og[(long)i * W + l] = (Y[it][lt][r] - mean) * rstd;
+                    if (i < H && l < W) og[i * W + l] = (Y[it][lt][r] - mean) * rstd;
                 }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -896,7 +937,9 @@ static hipError_t launch_fa_sandwich_t(const FaSandwichArgs& a, hipStream_t s) {
     int ppb = 16;
     while (ppb > 4 && (long)a.B * a.heads * ((a.C + ppb - 1) / ppb) < 512) ppb >>= 1;
     dim3 grid((a.C + ppb - 1) / ppb, a.heads, a.B);
-    hipLaunchKernelGGL((fa_sandwich_kernel<HT, WT>), grid, dim3(256), lds, s, a, ppb);
+    const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.u) & 15) == 0);
+    if (vec) hipLaunchKernelGGL((fa_sandwich_kernel<HT, WT, true>), grid, dim3(256), lds, s, a, ppb);
+    else hipLaunchKernelGGL((fa_sandwich_kernel<HT, WT, false>), grid, dim3(256), lds, s, a, ppb);
     return hipGetLastError();
 }
 
@@ -935,11 +978,16 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 3, false>))
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, true>))
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, false>))
-    LNS_SET_LDS((fa_sandwich_kernel<1, 1>))
-    LNS_SET_LDS((fa_sandwich_kernel<1, 2>))
-    LNS_SET_LDS((fa_sandwich_kernel<2, 2>))
-    LNS_SET_LDS((fa_sandwich_kernel<2, 3>))
-    LNS_SET_LDS((fa_sandwich_kernel<2, 1>))
+    LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
+    LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
+    LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))
+    LNS_SET_LDS((fa_sandwich_kernel<1, 2, false>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 2, true>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 2, false>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 3, true>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 3, false>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 1, true>))
+    LNS_SET_LDS((fa_sandwich_kernel<2, 1, false>))
     LNS_SET_LDS(fa_lrk_kernel)
     LNS_SET_LDS(fa_pool_kernel)
     LNS_SET_LDS(fa_reducer_kernel)

@@ -107,8 +107,8 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
     if (force_variant >= 0) cands = {force_variant};
     else if (Cout <= 32) cands = {CV_S32};
     else if (Cout <= 64) cands = {CV_L64, CV_M64, CV_S64};
-    else if (getenv("LNS_CONV_NO_128")) cands = {CV_L64, CV_M64, CV_S64};   // tuning knob (tile choice only)
-    else cands = {CV_L128, CV_M128, CV_S64};
+    else if (getenv("LNS_CONV_USE_128")) cands = {CV_L128, CV_M128, CV_S64};   // tuning knob (tile choice only)
+    else cands = {CV_L64, CV_M64, CV_S64};   // 64-cout tiles at 2 waves/SIMD beat 128-cout tiles at 1 (measured)
     g.kc_log2 = conv_pick_kc_log2(k, stride, kc_log2_pack);
     static const int pref[] = {5, 6, 4, 7, 3, 8};   // log2 BW preference on ties: 32,64,16,128,8,256
     bool found = false;

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     constexpr int MAXE = KS == 3 ? CONV_MAXE3 : CONV_MAXE1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int KC = 1 << a.kc_log2;
+    constexpr int KC = KS == 3 ? 4 : 16;   // channels per stage: compile-time (see conv_pick_kc_log2)
+    constexpr int KC_LOG2 = KS == 3 ? 2 : 4;
     const int PH = a.PH, PW = a.PW;
     const int PLANE = KS == 3 ? PH * PW : TN;
     const int xs_floats = (KC * PLANE + 3) & ~3;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     for (int i = 0; i < CONV_MAXW; ++i) {
         const int fi = tid + i * NTHR;
         const int row = fi / V4, c4 = fi - row * V4;
-        const int tap = row >> a.kc_log2, k = row & (KC - 1);
+        const int tap = row >> KC_LOG2, k = row & (KC - 1);
         wdesc[i] = (fi < nw4) ? ((tap * a.Cin_pad + k) * a.Cout_pad + ct * TM + c4 * 4) : -1;
     }
 
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
         for (int t = 0; t < KS * KS; ++t) {
             const float* wsp = wbase + t * KC * TM;
             const float* xsp = xbase + toff[t];
-#pragma unroll 8
+#pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
                 float av[MT], bv[NT];
 #pragma unroll
@@ -337,12 +338,13 @@ static const ConvVariantInfo kConvInfo[CV_COUNT] = {
 
 ConvVariantInfo conv_variant_info(int v) { return kConvInfo[v]; }
 
-// Stage depth (channels per LDS stage).  It is a function of the kernel size and stride ONLY
-// (3x3: 4, 3x3 stride 2: 2, 1x1: 16), never of the tile variant or batch: the fp32
+// Stage depth (channels per LDS stage).  It is a function of the kernel size ONLY
+// (3x3: 4, 1x1: 16), never of the tile variant or batch: the fp32
 // accumulation order of an output element is then independent of how the launch was tiled,
 // so a trajectory's result is bit-identical whatever batch (or GPU shard) it is computed in.
 int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
-    int lg = ks == 3 ? (stride == 1 ? 2 : 1) : 4;
+    (void)stride;
+    int lg = ks == 3 ? 2 : 4;     // must match the KC constants compiled into conv_mfma_kernel
     return lg < kc_log2_max ? lg : kc_log2_max;
 }
 
@@ -357,7 +359,8 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 bool conv_fits(int variant, const ConvArgs& a) {
     const long KC = 1 << a.kc_log2;
     const int TM = kConvInfo[variant].TM, TN = kConvInfo[variant].TN;
-    if (conv_lds_bytes(variant, a) > 150 * 1024 || (a.Cin_pad % KC) != 0 || KC < 2) return false;
+    if (KC != (a.ks == 3 ? 4 : 16)) return false;
+    if (conv_lds_bytes(variant, a) > 150 * 1024 || (a.Cin_pad % KC) != 0) return false;
     if ((long)a.ks * a.ks * KC * TM > (long)(a.ks == 3 ? CONV_MAXW : 2) * 1024) return false;
     if (a.ks == 3) return KC * a.PH * a.PW <= (long)CONV_MAXE3 * 256;
     return KC * TN <= (long)CONV_MAXE1 * 256;

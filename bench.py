@@ -49,6 +49,16 @@ def cpu_baseline(args, sd, B, T):
     import lns_oracle
     from lns_amd import filler
     x = filler.normal("xcpu", (B, args.in_channels, args.Ly, args.Lx), 3)
+    # threads: the cores this process may actually use (affinity and cgroup quota), not all
+    # hardware threads of the host
+    ncpu = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    lns_oracle.set_num_threads(ncpu)
     orc = lns_oracle.OracleDynamics(args, sd)
     orc.predict(x[:1], 1, to_x=True)            # warm the pages / thread pool
     t0 = time.perf_counter()
@@ -98,31 +108,21 @@ def main():
     C, H, W = eng.latent_shape()
     out = torch.empty((B, T, args.in_channels, args.Ly, args.Lx), dtype=torch.float32, device=dev)
     gather = world > 1 and not a.no_gather
-    chunk = max(1, min(a.gather_chunk, T))
+    from lns_amd import parallel
+
+    def _rollout_latent(z, steps, buf):
+        return eng.rollout_latent(z, steps, to_x=True, out=buf)[1]
+    chunked = None
     if gather:
-        comm_stream = torch.cuda.Stream(device=dev)
-        n_chunks = (T + chunk - 1) // chunk
-        chunk_bufs = [torch.empty((B, min(chunk, T - i * chunk), args.in_channels, args.Ly, args.Lx),
-                                  dtype=torch.float32, device=dev) for i in range(n_chunks)]
-        gathered = [torch.empty((world,) + tuple(cb.shape), dtype=torch.float32, device=dev) for cb in chunk_bufs]
+        chunked = parallel.ChunkedGatherRollout(eng.encode, _rollout_latent, (args.in_channels, args.Ly, args.Lx),
+                                                B, T, a.gather_chunk, dev, gather=True)
 
     def one_pass():
-        if not gather:
+        if chunked is None:
             eng.rollout(x, T, to_x=True, out=out)
-            return
-        # chunked rollout; each finished step block is all-gathered on a side stream
-        z = eng.encode(x)
-        works = []
-        for i, cb in enumerate(chunk_bufs):
-            _, z = eng.rollout_latent(z, cb.shape[1], to_x=True, out=cb)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                works.append(dist.all_gather_into_tensor(gathered[i], cb, async_op=True))
-        for w in works:
-            w.wait()
-        torch.cuda.current_stream().wait_stream(comm_stream)
+        else:
+            # chunked rollout; each finished step block is all-gathered on a side stream
+            chunked.run(x)
 
     def barrier():
         if world > 1:

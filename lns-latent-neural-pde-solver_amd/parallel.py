@@ -1,0 +1,71 @@
+"""Trajectory sharding of the rollout over the GPUs of one node.
+
+The path has no cross-trajectory arithmetic (GroupNorm / InstanceNorm / LayerNorm / attention
+are per sample), so rank r simply owns a contiguous slice of the batch and runs
+the whole rollout on it: no collective in the data path.  When every rank wants the full
+result, finished step-blocks are all-gathered (RCCL over xGMI on GPUs; gloo in CPU tests) on
+a side stream while the remaining steps are still being computed.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(global_batch: int, rank: int, world: int):
+    """Contiguous split; the first (global_batch % world) ranks get one more trajectory."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def chunk_lengths(T: int, chunk: int):
+    chunk = max(1, min(chunk, T))
+    return [min(chunk, T - i) for i in range(0, T, chunk)]
+
+
+class ChunkedGatherRollout:
+    """encode once, then rollout in step-blocks; block i is gathered while block i+1 runs.
+
+    encode(x) -> z ; rollout_latent(z, steps, out) -> z_next  (out: [B, steps, C, H, W], written in place).
+    All ranks must hold the same local batch size (all_gather_into_tensor)."""
+
+    def __init__(self, encode, rollout_latent, frame_shape, B, T, chunk, device, group=None, gather=True):
+        self.encode, self.rollout_latent = encode, rollout_latent
+        self.group, self.gather = group, gather
+        self.world = dist.get_world_size(group) if (gather and dist.is_initialized()) else 1
+        self.lens = chunk_lengths(T, chunk)
+        self.bufs = [torch.empty((B, n) + tuple(frame_shape), dtype=torch.float32, device=device) for n in self.lens]
+        self.gathered = None
+        self.comm_stream = None
+        if self.gather and self.world > 1:
+            # concatenated along dim 0 in rank order (the form every backend accepts)
+            self.gathered = [torch.empty((self.world * b.shape[0],) + tuple(b.shape[1:]), dtype=torch.float32,
+                                         device=device) for b in self.bufs]
+            if torch.device(device).type == "cuda":
+                self.comm_stream = torch.cuda.Stream(device=device)
+
+    def run(self, x):
+        z = self.encode(x)
+        works = []
+        for i, buf in enumerate(self.bufs):
+            z = self.rollout_latent(z, buf.shape[1], buf)
+            if self.gathered is None:
+                continue
+            if self.comm_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    works.append(dist.all_gather_into_tensor(self.gathered[i], buf, group=self.group, async_op=True))
+            else:
+                works.append(dist.all_gather_into_tensor(self.gathered[i], buf, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        return self.bufs
+
+    def assemble(self):
+        """[world*B, T, C, H, W] on every rank (concatenation in rank order), for checks."""
+        if self.gathered is None:
+            return torch.cat(self.bufs, dim=1)
+        return torch.cat(self.gathered, dim=1)

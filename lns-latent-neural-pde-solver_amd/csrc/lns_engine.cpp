@@ -506,6 +506,120 @@ struct Planner {
         return out;
     }
 
+    // materialise a pending GroupNorm scale/shift (+ activation) -- used where the consumer's
+    // prologue cannot express it (GELU prologue of the conditional block)
+    TRef emit_apply(TRef& x, int act, const std::string& name) {
+        TRef y = alloc_t(x.C, x.H, x.W);
+        Op op;
+        op.type = OP_APPLY; op.name = name; op.cls = CLS_MISC;
+        op.ap.x = as_ptr<const float>(x.ptr); op.ap.x_bs = x.bs; op.ap.ss = as_ptr<const float>(x.ss);
+        op.ap.act = act; op.ap.y = as_ptr<float>(y.ptr); op.ap.B = B; op.ap.C = x.C; op.ap.HW = x.H * x.W;
+        op.bytes = 8.0 * B * x.C * x.H * x.W;
+        plan->ops.push_back(op);
+        return y;
+    }
+
+    // conditional propagator, step-invariant part: cond_emb_proj(fourier_embedding(param))
+    // train_stage2_twophase_conditional.py:116, modules/cond_utils.py:19-38
+    uint64_t cond_ce = 0; size_t cond_ce_off = 0; bool cond_ce_live = false;
+    void emit_cond_base() {
+        const lns_config& c = e->cfg;
+        const int E = c.cond_emb_dim, half = E / 2;
+        std::vector<float> fr(half);
+        for (int i = 0; i < half; ++i) fr[i] = (float)std::exp(-std::log(10000.0) * (double)((float)i) / (double)half);
+        const std::string p = c.prop_prefix;
+        Op op;
+        op.type = OP_CONDBASE; op.name = p + "cond_emb_proj"; op.cls = CLS_COND;
+        op.cb.param = as_ptr<const float>(tag(SP_EXT0 + EX_PARAM, 0)); op.cb.B = B; op.cb.E = E;
+        op.cb.freqs = as_ptr<const float>(const_floats(fr));
+        op.cb.w0_t = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.0.weight")));
+        op.cb.b0 = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.0.bias")));
+        op.cb.w2_t = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.2.weight")));
+        op.cb.b2 = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.2.bias")));
+        cond_ce_off = arena.alloc((size_t)B * E * 4);
+        cond_ce = tag(SP_WS, cond_ce_off); cond_ce_live = true;
+        op.cb.ce = as_ptr<float>(cond_ce);
+        plan->ops.push_back(op);
+    }
+
+    // conditional DilatedResidualBlock: train_stage2_twophase_conditional.py:25-75
+    TRef lower_condblock(const Layer& l, TRef x) {
+        const lns_config& c = e->cfg;
+        const int D = l.C, E = c.cond_emb_dim;
+        const std::string q = l.name;
+        const size_t emb_off = arena.alloc((size_t)B * D * 4), mul_off = arena.alloc((size_t)B * D * 4);
+        {
+            Op op;
+            op.type = OP_CONDBLK; op.name = q + ".cond"; op.cls = CLS_COND;
+            op.ck.ce = as_ptr<const float>(cond_ce); op.ck.B = B; op.ck.E = E; op.ck.D = D;
+            op.ck.wce_t = as_ptr<const float>(vecp(vec_id(q + ".cond_emb.weight")));
+            op.ck.bce = as_ptr<const float>(vecp(vec_id(q + ".cond_emb.bias")));
+            op.ck.gn_g = as_ptr<const float>(vecp(vec_id(q + ".cond_conv2.0.weight")));
+            op.ck.gn_b = as_ptr<const float>(vecp(vec_id(q + ".cond_conv2.0.bias")));
+            op.ck.c1_t = as_ptr<const float>(vecp(vec_id(q + ".cond_conv2.1.weight")));
+            op.ck.c1_b = as_ptr<const float>(vecp(vec_id(q + ".cond_conv2.1.bias")));
+            op.ck.c3_t = as_ptr<const float>(vecp(vec_id(q + ".cond_conv2.3.weight")));
+            op.ck.c3_b = as_ptr<const float>(vecp(vec_id(q + ".cond_conv2.3.bias")));
+            op.ck.emb = as_ptr<float>(tag(SP_WS, emb_off)); op.ck.mul = as_ptr<float>(tag(SP_WS, mul_off));
+            plan->ops.push_back(op);
+        }
+        TRef xin = x; xin.owned = false;
+        emit_gn(xin, 1, 1e-5f, l.p_g1, l.p_b1, 0, q + ".conv1.0");
+        TRef h1 = conv_same3(xin, l.p_c1, 1, l.mode_y, l.mode_x, ACT_GELU, nullptr, 0, q + ".conv1.1");
+        free_t(xin);
+        TRef h2 = conv_same3(h1, l.p_c3, l.dil, l.mode_y, l.mode_x, ACT_NONE, nullptr, tag(SP_WS, emb_off), q + ".conv1.3");
+        free_t(h1);
+        emit_gn(h2, 1, 1e-5f, l.c_g, l.c_b, 0, q + ".cond_conv1.0");
+        TRef h3 = emit_apply(h2, ACT_GELU, q + ".cond_conv1.1");
+        free_t(h2);
+        TRef x1 = conv_same3(h3, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2");
+        free_t(h3);
+        TRef xin2 = x1; xin2.owned = false;
+        emit_gn(xin2, 1, 1e-5f, l.p_g2, l.p_b2, tag(SP_WS, mul_off), q + ".ffn.0");
+        TRef f1 = conv_same1(xin2, l.p_f1, ACT_GELU, nullptr, nullptr, q + ".ffn.1");
+        free_t(xin2);
+        TRef out = conv_same1(f1, l.p_f3, ACT_NONE, &x1, nullptr, q + ".ffn.3");
+        free_t(f1); free_t(x1);
+        arena.release(emb_off); arena.release(mul_off);
+        return out;
+    }
+
+    // FourierBasicBlock: x + gelu(SpectralConv2d(x) + conv1x1(x))   modules/basics.py:574-583
+    TRef lower_fourier(const Layer& l, TRef x, const TRef* out_forced) {
+        if (x.pending()) throw std::runtime_error("FourierBasicBlock input must be materialised");
+        if (l.cin != x.C || l.cin != l.cout) throw std::runtime_error("FourierBasicBlock needs in == out channels: " + l.name);
+        const int C = x.C, H = x.H, W = x.W, m1 = l.m1, m2 = l.m2;
+        if (2 * m1 > H || m2 > W / 2 + 1) throw std::runtime_error("too many Fourier modes for this resolution: " + l.name);
+        TRef x2 = conv_same1(x, l.f_conv, ACT_NONE, nullptr, nullptr, l.name + ".conv");
+        TRef x1 = alloc_t(C, H, W);
+        const size_t t1 = arena.alloc((size_t)B * C * H * m2 * 2 * 4), xf = arena.alloc((size_t)B * C * 2 * m1 * m2 * 2 * 4),
+                     of = arena.alloc((size_t)B * C * 2 * m1 * m2 * 2 * 4);
+        {
+            Op op;
+            op.type = OP_SPECTRAL; op.name = l.name + ".fourier"; op.cls = CLS_SPECTRAL;
+            memset(&op.sp, 0, sizeof op.sp);
+            op.sp.x = as_ptr<const float>(x.ptr); op.sp.x_bs = x.bs; op.sp.B = B; op.sp.Cin = C; op.sp.Cout = C;
+            op.sp.H = H; op.sp.W = W; op.sp.m1 = m1; op.sp.m2 = m2;
+            op.sp.w1 = as_ptr<const float>(vecp(l.f_w1)); op.sp.w2 = as_ptr<const float>(vecp(l.f_w2));
+            op.sp.t1 = as_ptr<float>(tag(SP_WS, t1)); op.sp.xf = as_ptr<float>(tag(SP_WS, xf));
+            op.sp.of = as_ptr<float>(tag(SP_WS, of)); op.sp.y = as_ptr<float>(x1.ptr);
+            op.flops = 8.0 * B * C * ((double)H * W * m2 + 2.0 * H * m1 * m2) * 2 + 8.0 * B * C * C * 2.0 * m1 * m2;
+            plan->ops.push_back(op);
+        }
+        arena.release(t1); arena.release(xf); arena.release(of);
+        TRef out = out_forced ? *out_forced : alloc_t(C, H, W);
+        {
+            Op op;
+            op.type = OP_FCOMBINE; op.name = l.name + ".combine"; op.cls = CLS_MISC;
+            op.fc.a = as_ptr<const float>(x1.ptr); op.fc.b = as_ptr<const float>(x2.ptr); op.fc.e = nullptr;
+            op.fc.skip = as_ptr<const float>(x.ptr); op.fc.skip_bs = x.bs; op.fc.y = as_ptr<float>(out.ptr);
+            op.fc.y_bs = out.bs; op.fc.B = B; op.fc.C = C; op.fc.HW = H * W;
+            plan->ops.push_back(op);
+        }
+        free_t(x1); free_t(x2);
+        return out;
+    }
+
     // sequential program ---------------------------------------------------------
     void lower_sequence(const std::vector<Layer>& L, TRef in, const TRef& out_ext) {
         TRef cur = in;
@@ -546,6 +660,10 @@ struct Planner {
                 case LT_SA: nxt = lower_sa(l, cur); free_t(cur); trace(l.name, nxt); break;
                 case LT_FA: nxt = lower_fa(l, cur); free_t(cur); trace(l.name, nxt); break;
                 case LT_PROPBLOCK: nxt = lower_propblock(l, cur); free_t(cur); trace(l.name, nxt); break;
+                case LT_CONDBLOCK:
+                    if (!cond_ce_live) emit_cond_base();
+                    nxt = lower_condblock(l, cur); free_t(cur); trace(l.name, nxt); break;
+                case LT_FOURIER: nxt = lower_fourier(l, cur, nullptr); free_t(cur); trace(l.name, nxt); break;
                 default: throw std::runtime_error("layer type not supported by this build: " + l.name);
             }
             if (last && l.type != LT_CONV) throw std::runtime_error("program must end in a convolution");
@@ -567,6 +685,7 @@ struct Planner {
             };
             if (op.type == OP_CONV) { rebase(op.conv.rowmap); rebase(op.conv.colmap); }
             if (op.type == OP_FALRK) rebase(op.fl.cs);
+            if (op.type == OP_CONDBASE) rebase(op.cb.freqs);
         }
         plan->arena_bytes = arena.high;
     }
@@ -747,6 +866,33 @@ struct Runner {
                     FaSandwichArgs a = op.fs;
                     fix(a.u, B); fix(a.kx, B); fix(a.ky, B); fix(a.out, B);
                     rc = launch_fa_sandwich(a, stream);
+                    break;
+                }
+                case OP_CONDBASE: {
+                    CondBaseArgs a = op.cb;
+                    fix(a.param, B); fix(a.freqs, B); fix(a.w0_t, B); fix(a.b0, B); fix(a.w2_t, B); fix(a.b2, B); fix(a.ce, B);
+                    rc = launch_cond_base(a, stream);
+                    break;
+                }
+                case OP_CONDBLK: {
+                    CondBlockArgs a = op.ck;
+                    fix(a.ce, B); fix(a.wce_t, B); fix(a.bce, B); fix(a.gn_g, B); fix(a.gn_b, B); fix(a.c1_t, B);
+                    fix(a.c1_b, B); fix(a.c3_t, B); fix(a.c3_b, B); fix(a.emb, B); fix(a.mul, B);
+                    rc = launch_cond_block(a, stream);
+                    break;
+                }
+                case OP_APPLY: { ApplyArgs a = op.ap; fix(a.x, B); fix(a.ss, B); fix(a.y, B); fixbs(a.x_bs, B); rc = launch_apply(a, stream); break; }
+                case OP_SPECTRAL: {
+                    SpectralArgs a = op.sp;
+                    fix(a.x, B); fix(a.w1, B); fix(a.w2, B); fix(a.emb, B); fix(a.t1, B); fix(a.xf, B); fix(a.of, B); fix(a.y, B);
+                    fixbs(a.x_bs, B);
+                    rc = launch_spectral(a, stream);
+                    break;
+                }
+                case OP_FCOMBINE: {
+                    FourierCombineArgs a = op.fc;
+                    fix(a.a, B); fix(a.b, B); fix(a.e, B); fix(a.skip, B); fix(a.y, B); fixbs(a.skip_bs, B); fixbs(a.y_bs, B);
+                    rc = launch_fourier_combine(a, stream);
                     break;
                 }
                 case OP_TRACE: {

@@ -68,8 +68,8 @@ struct Layer {
 enum Space { SP_NULL = 0, SP_WS = 1, SP_WT = 2, SP_CT = 3, SP_EXT0 = 4 };   // ext slots: 4..11
 enum ExtSlot { EX_IN = 0, EX_OUT = 1, EX_PARAM = 2, EX_COUNT = 3 };
 
-enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FALRK, OP_FASAND, OP_COND, OP_SPECTRAL,
-              OP_FCOMBINE, OP_TRACE };
+enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FALRK, OP_FASAND, OP_CONDBASE, OP_CONDBLK,
+              OP_APPLY, OP_SPECTRAL, OP_FCOMBINE, OP_TRACE };
 
 struct Op {
     OpType type;
@@ -85,7 +85,9 @@ struct Op {
     FaReducerArgs fr;
     FaLrkArgs fl;
     FaSandwichArgs fs;
-    CondArgs cd;
+    CondBaseArgs cb;
+    CondBlockArgs ck;
+    ApplyArgs ap;
     SpectralArgs sp;
     FourierCombineArgs fc;
     // trace

@@ -106,35 +106,44 @@ struct FaSandwichArgs {
 hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s);
 size_t fa_sandwich_lds_bytes(int H, int W);
 
-// conditional propagator: per-sample embedding MLPs (step-invariant) ---------
-struct CondArgs {
-    const float* param; int B, E /*cond_emb_dim*/, D /*prop_n_embd*/, nblk;
-    const float* p0_wt; const float* p0_b;   // cond_emb_proj.0 : [E][E] in-major, [E]
-    const float* p2_wt; const float* p2_b;   // cond_emb_proj.2
-    // per block (arrays of nblk device pointers are avoided: weights are packed contiguously)
-    const float* blk;      // per block: ce_wt [E][D], ce_b [D], gn_g [D], gn_b [D], c1_wt [D][D], c1_b [D], c3_wt [D][D], c3_b [D]
-    long blk_stride;
-    float* emb;            // [nblk][B][D]   cond_emb(cond)            (added after conv1)
-    float* mul;            // [nblk][B][D]   1 + cond_conv2(emb)       (pre-multiplier of ffn input)
+// conditional propagator: per-sample embedding MLPs (tiny; step-invariant) ------
+struct CondBaseArgs {            // ce = W2 gelu(W0 fourier_embedding(param) + b0) + b2
+    const float* param; int B, E;
+    const float* freqs;          // [E/2]
+    const float* w0_t; const float* b0; const float* w2_t; const float* b2;   // in-major [E][E]
+    float* ce;                   // [B][E]
 };
-hipError_t launch_cond(const CondArgs& a, hipStream_t s);
+hipError_t launch_cond_base(const CondBaseArgs& a, hipStream_t s);
+struct CondBlockArgs {           // emb = Wce ce + bce ; mul = 1 + conv1(gelu(conv1(GN1(emb))))
+    const float* ce; int B, E, D;
+    const float* wce_t; const float* bce;          // [E][D], [D]
+    const float* gn_g; const float* gn_b;          // [D]
+    const float* c1_t; const float* c1_b;          // [D][D] in-major, [D]
+    const float* c3_t; const float* c3_b;
+    float* emb; float* mul;                        // [B][D]
+};
+hipError_t launch_cond_block(const CondBlockArgs& a, hipStream_t s);
 
-// Fourier blocks (opt-in): truncated DFT as dense contractions ---------------
+// y = act(x * scale[b,c] + shift[b,c])  (materialises a pending GroupNorm + activation)
+struct ApplyArgs { const float* x; long x_bs; const float* ss; int act; float* y; int B, C, HW; };
+hipError_t launch_apply(const ApplyArgs& a, hipStream_t s);
+
+// Fourier blocks (opt-in): truncated DFT as dense contractions --------------------
+//   xf = DFT_H(DFT_W(x)) restricted to rows {0..m1-1, H-m1..H-1} x cols {0..m2-1}
+//   of[b,o] = sum_i xf[b,i] * w{1,2}[i,o] (* emb[b])   ;   y = irfft2(of)
 struct SpectralArgs {
-    const float* x; int B, Cin, Cout, H, W, m1, m2;
+    const float* x; long x_bs; int B, Cin, Cout, H, W, m1, m2;
     const float* w1; const float* w2;     // [Cin][Cout][m1][m2][2]
-    const float* emb;                     // [B][m1][m2][2][2] complex cond scaling or null
-    const float* tw_h;                    // [H][H][2] cos/sin(2*pi*k*y/H)
-    const float* tw_w;                    // [W][W][2]
-    float* xf;                            // workspace [B][Cin][2*m1][m2][2]
-    float* of;                            // workspace [B][Cout][2*m1][m2][2]
-    float* tmp;                           // workspace [B][max(Cin,Cout)][H][m2][2]
-    float* y;                             // [B][Cout][H][W]   (spectral conv output)
+    const float* emb;                     // [B][m1][m2][2(lo,hi)][2(re,im)] conditional scaling or null
+    float* t1;                            // [B][max(Cin,Cout)][H][m2][2]
+    float* xf;                            // [B][Cin][2*m1][m2][2]
+    float* of;                            // [B][Cout][2*m1][m2][2]
+    float* y;                             // [B][Cout][H][W]
 };
 hipError_t launch_spectral(const SpectralArgs& a, hipStream_t s);
 
 // y = skip + gelu(a + b + e[b,c])
-struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; float* y; int B, C, HW; };
+struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; long skip_bs; float* y; long y_bs; int B, C, HW; };
 hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s);
 
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU

@@ -957,6 +957,234 @@ hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s) {
 }
 
 // ===========================================================================
+// Conditional propagator: per-sample embedding MLPs.  One block per sample; the
+// vectors are <= 128 long, the matrices are stored in-major so lanes read
+// consecutive outputs.  train_stage2_twophase_conditional.py:66-75,114-116,
+// modules/cond_utils.py:19-38.
+// ===========================================================================
+__global__ __launch_bounds__(128) void cond_base_kernel(CondBaseArgs a) {
+    __shared__ float v0[256], v1[256];
+    const int b = blockIdx.x, tid = threadIdx.x, E = a.E, half = E / 2;
+    const float t = a.param[b];
+    for (int i = tid; i < E; i += 128) {
+        float val = 0.0f;
+        if (i < half) val = cosf(t * a.freqs[i]);
+        else if (i < 2 * half) val = sinf(t * a.freqs[i - half]);
+        v0[i] = val;
+    }
+    __syncthreads();
+    for (int o = tid; o < E; o += 128) {
+        float acc = a.b0[o];
+        for (int i = 0; i < E; ++i) acc += a.w0_t[i * E + o] * v0[i];
+        v1[o] = act_apply(acc, ACT_GELU);
+    }
+    __syncthreads();
+    for (int o = tid; o < E; o += 128) {
+        float acc = a.b2[o];
+        for (int i = 0; i < E; ++i) acc += a.w2_t[i * E + o] * v1[i];
+        a.ce[(long)b * E + o] = acc;
+    }
+}
+hipError_t launch_cond_base(const CondBaseArgs& a, hipStream_t s) {
+    if (a.E > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cond_base_kernel, dim3(a.B), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(128) void cond_block_kernel(CondBlockArgs a) {
+    __shared__ float ce[256], e[512], h1[512], red[2];
+    const int b = blockIdx.x, tid = threadIdx.x, E = a.E, D = a.D;
+    for (int i = tid; i < E; i += 128) ce[i] = a.ce[(long)b * E + i];
+    __syncthreads();
+    for (int o = tid; o < D; o += 128) {
+        float acc = a.bce[o];
+        for (int i = 0; i < E; ++i) acc += a.wce_t[i * D + o] * ce[i];
+        e[o] = acc;
+        a.emb[(long)b * D + o] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {   // GroupNorm(1, D) over the D values of this sample (biased variance)
+        float s = 0.0f;
+        for (int i = 0; i < D; ++i) s += e[i];
+        const float mean = s / (float)D;
+        float q = 0.0f;
+        for (int i = 0; i < D; ++i) { const float d = e[i] - mean; q += d * d; }
+        red[0] = mean; red[1] = 1.0f / sqrtf(q / (float)D + 1e-5f);
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += 128) e[i] = (e[i] - red[0]) * red[1] * a.gn_g[i] + a.gn_b[i];
+    __syncthreads();
+    for (int o = tid; o < D; o += 128) {
+        float acc = a.c1_b[o];
+        for (int i = 0; i < D; ++i) acc += a.c1_t[i * D + o] * e[i];
+        h1[o] = act_apply(acc, ACT_GELU);
+    }
+    __syncthreads();
+    for (int o = tid; o < D; o += 128) {
+        float acc = a.c3_b[o];
+        for (int i = 0; i < D; ++i) acc += a.c3_t[i * D + o] * h1[i];
+        a.mul[(long)b * D + o] = 1.0f + acc;
+    }
+}
+hipError_t launch_cond_block(const CondBlockArgs& a, hipStream_t s) {
+    if (a.E > 256 || a.D > 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cond_block_kernel, dim3(a.B), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void apply_kernel(ApplyArgs a) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float sc = a.ss ? a.ss[((long)b * a.C + c) * 2] : 1.0f;
+    const float sh = a.ss ? a.ss[((long)b * a.C + c) * 2 + 1] : 0.0f;
+    const float* xs = a.x + (long)b * a.x_bs + (long)c * a.HW;
+    float* ys = a.y + ((long)b * a.C + c) * a.HW;
+    for (int i = threadIdx.x; i < a.HW; i += 256) ys[i] = act_apply(xs[i] * sc + sh, a.act);
+}
+hipError_t launch_apply(const ApplyArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(apply_kernel, dim3(a.C, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// Spectral convolution with mode truncation (FNO layer) as dense truncated DFTs.
+// modules/basics.py:126-149 ; conditional scaling modules/fourier_cond.py:55-81.
+// Twiddles are evaluated with sincospif on exact rational arguments ((k*n) mod N)/N.
+// ===========================================================================
+__device__ __forceinline__ void twiddle(int k, int n, int N, float sign, float& c, float& s) {
+    const int r = (int)(((long)k * n) % N);
+    sincospif(2.0f * (float)r / (float)N, &s, &c);
+    s *= sign;
+}
+// A: t1[b,c,y,k2] = sum_x x[b,c,y,x] e^{-2 pi i k2 x / W}
+__global__ __launch_bounds__(256) void spec_rows_fwd(SpectralArgs a) {
+    const long n = (long)a.B * a.Cin * a.H * a.m2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k2 = (int)(i % a.m2);
+        long r = i / a.m2;
+        const int y = (int)(r % a.H); r /= a.H;
+        const int c = (int)(r % a.Cin);
+        const int b = (int)(r / a.Cin);
+        const float* xr = a.x + (long)b * a.x_bs + ((long)c * a.H + y) * a.W;
+        float re = 0.0f, im = 0.0f;
+        for (int x = 0; x < a.W; ++x) {
+            float cs, sn;
+            twiddle(k2, x, a.W, -1.0f, cs, sn);
+            re += xr[x] * cs; im += xr[x] * sn;
+        }
+        a.t1[i * 2] = re; a.t1[i * 2 + 1] = im;
+    }
+}
+// B: xf[b,c,kk,k2] = sum_y t1[b,c,y,k2] e^{-2 pi i k1 y / H},  k1 = kk (kk < m1) or H - 2 m1 + kk
+__global__ __launch_bounds__(256) void spec_cols_fwd(SpectralArgs a) {
+    const int M1 = 2 * a.m1;
+    const long n = (long)a.B * a.Cin * M1 * a.m2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k2 = (int)(i % a.m2);
+        long r = i / a.m2;
+        const int kk = (int)(r % M1); r /= M1;
+        const int k1 = kk < a.m1 ? kk : a.H - M1 + kk;
+        const float* tp = a.t1 + (r * a.H * a.m2 + k2) * 2;
+        float re = 0.0f, im = 0.0f;
+        for (int y = 0; y < a.H; ++y) {
+            float cs, sn;
+            twiddle(k1, y, a.H, -1.0f, cs, sn);
+            const float tr = tp[(long)y * a.m2 * 2], ti = tp[(long)y * a.m2 * 2 + 1];
+            re += tr * cs - ti * sn; im += tr * sn + ti * cs;
+        }
+        a.xf[i * 2] = re; a.xf[i * 2 + 1] = im;
+    }
+}
+// C: of[b,o,kk,k2] = sum_i (xf[b,i,kk,k2] * emb[b]) * w[i,o,kk mod m1,k2]
+__global__ __launch_bounds__(256) void spec_mix(SpectralArgs a) {
+    const int M1 = 2 * a.m1;
+    const long n = (long)a.B * a.Cout * M1 * a.m2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k2 = (int)(i % a.m2);
+        long r = i / a.m2;
+        const int kk = (int)(r % M1); r /= M1;
+        const int o = (int)(r % a.Cout);
+        const int b = (int)(r / a.Cout);
+        const int hi = kk >= a.m1 ? 1 : 0, k1 = kk - hi * a.m1;
+        const float* w = hi ? a.w2 : a.w1;
+        float er = 1.0f, ei = 0.0f;
+        if (a.emb) {
+            const float* e = a.emb + ((((long)b * a.m1 + k1) * a.m2 + k2) * 2 + hi) * 2;   // [.., lo|hi, re|im]
+            er = e[0]; ei = e[1];
+        }
+        float re = 0.0f, im = 0.0f;
+        for (int c = 0; c < a.Cin; ++c) {
+            const float* xp = a.xf + ((((long)b * a.Cin + c) * M1 + kk) * a.m2 + k2) * 2;
+            const float xr = xp[0] * er - xp[1] * ei, xi = xp[0] * ei + xp[1] * er;
+            const float* wp = w + ((((long)c * a.Cout + o) * a.m1 + k1) * a.m2 + k2) * 2;
+            re += xr * wp[0] - xi * wp[1]; im += xr * wp[1] + xi * wp[0];
+        }
+        a.of[i * 2] = re; a.of[i * 2 + 1] = im;
+    }
+}
+// D: t1[b,o,y,k2] = sum_kk of[b,o,kk,k2] e^{+2 pi i k1 y / H}
+__global__ __launch_bounds__(256) void spec_cols_inv(SpectralArgs a) {
+    const int M1 = 2 * a.m1;
+    const long n = (long)a.B * a.Cout * a.H * a.m2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k2 = (int)(i % a.m2);
+        long r = i / a.m2;
+        const int y = (int)(r % a.H); r /= a.H;
+        const float* op = a.of + (r * M1 * a.m2 + k2) * 2;
+        float re = 0.0f, im = 0.0f;
+        for (int kk = 0; kk < M1; ++kk) {
+            const int k1 = kk < a.m1 ? kk : a.H - M1 + kk;
+            float cs, sn;
+            twiddle(k1, y, a.H, 1.0f, cs, sn);
+            const float tr = op[(long)kk * a.m2 * 2], ti = op[(long)kk * a.m2 * 2 + 1];
+            re += tr * cs - ti * sn; im += tr * sn + ti * cs;
+        }
+        a.t1[i * 2] = re; a.t1[i * 2 + 1] = im;
+    }
+}
+// E: y[b,o,y,x] = 1/(HW) sum_k2 c_k2 Re(t1[b,o,y,k2] e^{+2 pi i k2 x / W}),  c = 1 for DC / Nyquist else 2
+__global__ __launch_bounds__(256) void spec_rows_inv(SpectralArgs a) {
+    const long n = (long)a.B * a.Cout * a.H * a.W;
+    const float inv = 1.0f / (float)(a.H * a.W);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % a.W);
+        const long r = i / a.W;   // (b*Cout + o)*H + y
+        const float* tp = a.t1 + r * a.m2 * 2;
+        float acc = 0.0f;
+        for (int k2 = 0; k2 < a.m2; ++k2) {
+            float cs, sn;
+            twiddle(k2, x, a.W, 1.0f, cs, sn);
+            const float wgt = (k2 == 0 || 2 * k2 == a.W) ? 1.0f : 2.0f;
+            acc += wgt * (tp[k2 * 2] * cs - tp[k2 * 2 + 1] * sn);
+        }
+        a.y[i] = acc * inv;
+    }
+}
+hipError_t launch_spectral(const SpectralArgs& a, hipStream_t s) {
+    if (2 * a.m1 > a.H || a.m2 > a.W / 2 + 1) return hipErrorInvalidValue;
+    auto grid = [](long n) { long g = (n + 255) / 256; return dim3((unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g))); };
+    hipLaunchKernelGGL(spec_rows_fwd, grid((long)a.B * a.Cin * a.H * a.m2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(spec_cols_fwd, grid((long)a.B * a.Cin * 2 * a.m1 * a.m2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(spec_mix, grid((long)a.B * a.Cout * 2 * a.m1 * a.m2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(spec_cols_inv, grid((long)a.B * a.Cout * a.H * a.m2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(spec_rows_inv, grid((long)a.B * a.Cout * a.H * a.W), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void fourier_combine_kernel(FourierCombineArgs a) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const long base = ((long)b * a.C + c) * a.HW;
+    const float e = a.e ? a.e[(long)b * a.C + c] : 0.0f;
+    const float* sk = a.skip + (long)b * a.skip_bs + (long)c * a.HW;
+    float* ys = a.y + (long)b * a.y_bs + (long)c * a.HW;
+    for (int i = threadIdx.x; i < a.HW; i += 256)
+        ys[i] = sk[i] + act_apply(a.a[base + i] + a.b[base + i] + e, ACT_GELU);
+}
+hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(fourier_combine_kernel, dim3(a.C, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
 hipError_t init_kernels() {
     hipError_t e;
     const int maxlds = 160 * 1024;

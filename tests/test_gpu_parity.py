@@ -76,20 +76,23 @@ def test_fa_sandwich_kernel(case):
     assert gc.sandwich_case(**case) < KERNEL_TOL
 
 
-@pytest.mark.parametrize("preset", ["ns2d_mini", "ns2d_128"])
+@pytest.mark.parametrize("preset", ["ns2d_mini", "ns2d_128", "sw_half_periodic", "sw_96x192x5", "twophase",
+                                    "twophase_cond"])
 def test_every_layer_matches_oracle(preset):
     _need_gpu()
     import gpu_checks as gc
     from lns_amd import config, filler
     args = config.preset(preset)
     x = filler.normal("x", (2, args.in_channels, args.Ly, args.Lx), 7)
-    rows = gc.layer_trace_compare(args, 1, x)
+    param = filler.uniform01("param", 2, 7).astype(np.float32) if args.family == "twophase_cond" else None
+    rows = gc.layer_trace_compare(args, 1, x, param)
     assert len(rows) > 20
     bad = [r for r in rows if not (r[2] < STAGE_TOL)]
     assert not bad, bad
 
 
-GOLDEN_CASES = ["ns2d_mini", "ns2d_mini_zeros", "ns2d_mini_sa", "ns2d_mini_nocoarse", "ns2d_64", "ns2d_128"]
+GOLDEN_CASES = ["ns2d_mini", "ns2d_mini_zeros", "ns2d_mini_sa", "ns2d_mini_nocoarse", "ns2d_64", "ns2d_128",
+                "sw_half_periodic", "sw_96x192x5", "twophase", "twophase_cond", "ns2d_mini_fourier"]
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)

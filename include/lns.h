@@ -194,6 +194,17 @@ int lns_op_attention(const float* qkv, int B, int heads, int dim_head, int n, fl
 int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, int heads, int C,
                        int H, int W, float eps, int apply_instance_norm, float* out, void* stream);
 
+/* FourierBasicBlock (modules/basics.py:531-583) and CondFourierBasicBlock
+ * (modules/fourier_cond.py:84-117) as standalone ops (not reached by any shipped config):
+ *   y = x + gelu( irfft2(modes(rfft2(x)) . W{1,2} [* FreqLinear(cond)]) + conv1x1(x) [+ Linear(cond)] )
+ * x,y [B,C,H,W] device; all weights HOST pointers in the reference's state_dict layout:
+ *   w1,w2 [C,C,m1,m2,2]; conv_w [C,C,1,1], conv_b [C];
+ *   conditional only (cond != NULL, device [B,C]): freq_w [C,4*m1*m2], freq_b [1,4*m1*m2], lin_w [C,C], lin_b [C]. */
+int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int m2, const float* w1_host,
+                         const float* w2_host, const float* conv_w_host, const float* conv_b_host,
+                         const float* cond, const float* freq_w_host, const float* freq_b_host,
+                         const float* lin_w_host, const float* lin_b_host, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1322,4 +1322,53 @@ int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, 
     return LNS_OK;
 }
 
+int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int m2, const float* w1_host,
+                         const float* w2_host, const float* conv_w_host, const float* conv_b_host, const float* cond,
+                         const float* freq_w_host, const float* freq_b_host, const float* lin_w_host,
+                         const float* lin_b_host, float* y, void* stream) {
+    if (!x || !y || !w1_host || !w2_host || !conv_w_host || B <= 0 || 2 * m1 > H || m2 > W / 2 + 1) return LNS_EINVAL;
+    if (cond && (!freq_w_host || !freq_b_host || !lin_w_host || !lin_b_host)) return LNS_EINVAL;
+    OPCHK(init_kernels());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nw = (size_t)C * C * m1 * m2 * 2, nf = (size_t)4 * m1 * m2;
+    const size_t t1n = (size_t)B * C * H * m2 * 2, xfn = (size_t)B * C * 2 * m1 * m2 * 2, act = (size_t)B * C * H * W;
+    // one scratch allocation: [w1 | w2 | freq_w | freq_b | lin_w | lin_b | emb | e | t1 | xf | of | x1 | x2]
+    std::vector<size_t> sz = {nw, nw, (size_t)C * nf, nf, (size_t)C * C, (size_t)C, (size_t)B * nf, (size_t)B * C,
+                              t1n, xfn, xfn, act, act};
+    std::vector<size_t> off(sz.size());
+    size_t tot = 0;
+    for (size_t i = 0; i < sz.size(); ++i) { off[i] = tot; tot += (sz[i] + 63) / 64 * 64; }
+    float* d = nullptr;
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&d), tot * 4));
+    OPCHK(hipMemcpy(d + off[0], w1_host, nw * 4, hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(d + off[1], w2_host, nw * 4, hipMemcpyHostToDevice));
+    if (cond) {
+        OPCHK(hipMemcpy(d + off[2], freq_w_host, (size_t)C * nf * 4, hipMemcpyHostToDevice));
+        OPCHK(hipMemcpy(d + off[3], freq_b_host, nf * 4, hipMemcpyHostToDevice));
+        OPCHK(hipMemcpy(d + off[4], lin_w_host, (size_t)C * C * 4, hipMemcpyHostToDevice));
+        OPCHK(hipMemcpy(d + off[5], lin_b_host, (size_t)C * 4, hipMemcpyHostToDevice));
+        // FreqLinear: h = cond @ weights[C, 4 m1 m2] + bias      (fourier_cond.py:25-29)
+        VecLinearArgs fl = {cond, d + off[2], d + off[3], d + off[6], B, C, (int)nf, 1, (int)nf};
+        OPCHK(launch_vec_linear(fl, s));
+        // emb_out = Linear(cond): weight [out, in]                (fourier_cond.py:104,111)
+        VecLinearArgs ll = {cond, d + off[4], d + off[5], d + off[7], B, C, C, C, 1};
+        OPCHK(launch_vec_linear(ll, s));
+    }
+    SpectralArgs sp;
+    memset(&sp, 0, sizeof sp);
+    sp.x = x; sp.x_bs = (long)C * H * W; sp.B = B; sp.Cin = C; sp.Cout = C; sp.H = H; sp.W = W; sp.m1 = m1; sp.m2 = m2;
+    sp.w1 = d + off[0]; sp.w2 = d + off[1]; sp.emb = cond ? d + off[6] : nullptr;
+    sp.t1 = d + off[8]; sp.xf = d + off[9]; sp.of = d + off[10]; sp.y = d + off[11];
+    OPCHK(launch_spectral(sp, s));
+    int rc = lns_op_conv2d(x, B, C, H, W, H, W, conv_w_host, conv_b_host, C, 1, 1, 1, 0, 0, 0, 0, 0, 0, nullptr, 0, 0,
+                           nullptr, nullptr, d + off[12], -1, stream);
+    if (rc) { (void)hipFree(d); return rc; }
+    FourierCombineArgs fc = {d + off[11], d + off[12], cond ? d + off[7] : nullptr, x, (long)C * H * W, y,
+                             (long)C * H * W, B, C, H * W};
+    OPCHK(launch_fourier_combine(fc, s));
+    OPCHK(hipStreamSynchronize(s));
+    (void)hipFree(d);
+    return LNS_OK;
+}
+
 }  // extern "C"

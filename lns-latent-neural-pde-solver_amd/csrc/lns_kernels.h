@@ -146,6 +146,10 @@ hipError_t launch_spectral(const SpectralArgs& a, hipStream_t s);
 struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; long skip_bs; float* y; long y_bs; int B, C, HW; };
 hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s);
 
+// out[b,o] = bias[o] + sum_i in[b,i] * w[i*ldo + o*ldi]   (tiny dense layer on per-sample vectors)
+struct VecLinearArgs { const float* in; const float* w; const float* bias; float* out; int B, In, Out, ldi, ldo; };
+hipError_t launch_vec_linear(const VecLinearArgs& a, hipStream_t s);
+
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
 
 }  // namespace lns

@@ -1184,6 +1184,19 @@ hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void vec_linear_kernel(VecLinearArgs a) {
+    const int b = blockIdx.y;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < a.Out; o += gridDim.x * 256) {
+        float acc = a.bias ? a.bias[o] : 0.0f;
+        for (int i = 0; i < a.In; ++i) acc += a.in[(long)b * a.In + i] * a.w[(long)i * a.ldo + (long)o * a.ldi];
+        a.out[(long)b * a.Out + o] = acc;
+    }
+}
+hipError_t launch_vec_linear(const VecLinearArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(vec_linear_kernel, dim3((a.Out + 255) / 256, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ===========================================================================
 hipError_t init_kernels() {
     hipError_t e;

@@ -1,0 +1,90 @@
+"""Drop-ins for the Fourier blocks as standalone modules (no shipped config
+reaches them, so they are exposed as ops with unit-level parity):
+  FourierBasicBlock      reference modules/basics.py:531-583 (+ SpectralConv2d :99-149)
+  CondFourierBasicBlock  reference modules/fourier_cond.py:84-117 (+ SpectralConv2d :32-81, FreqLinear :16-29)
+Same constructor arguments and state_dict keys; forward runs the HIP kernels through the C ABI."""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..dropin import _Node
+from .._lib import LnsError
+
+
+def _host(t):
+    a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+class _FourierBase(nn.Module):
+    def __init__(self, in_planes, planes, modes, residual=True, conditional=False):
+        super().__init__()
+        if len(modes) != 2:
+            raise NotImplementedError("only the 2-D block is on the accelerated path")
+        if in_planes != planes or not residual:
+            raise NotImplementedError("the accelerated block needs in_planes == planes and residual=True")
+        self.modes = list(modes)
+        m1, m2 = modes
+        scale = 1.0 / (in_planes * planes)
+        self.fourier = _Node()
+        self.fourier.weights1 = nn.Parameter(scale * torch.rand(in_planes, planes, m1, m2, 2), requires_grad=False)
+        self.fourier.weights2 = nn.Parameter(scale * torch.rand(in_planes, planes, m1, m2, 2), requires_grad=False)
+        self.conv = _Node()
+        b = 1.0 / np.sqrt(in_planes)
+        self.conv.weight = nn.Parameter(torch.empty(planes, in_planes, 1, 1).uniform_(-b, b), requires_grad=False)
+        self.conv.bias = nn.Parameter(torch.empty(planes).uniform_(-b, b), requires_grad=False)
+        if conditional:
+            fs = 1.0 / (in_planes + 4 * m1 * m2)
+            self.fourier.cond_emb = _Node()
+            self.fourier.cond_emb.weights = nn.Parameter(fs * torch.randn(in_planes, 4 * m1 * m2), requires_grad=False)
+            self.fourier.cond_emb.bias = nn.Parameter(torch.zeros(1, 4 * m1 * m2), requires_grad=False)
+            self.cond_emb = _Node()
+            self.cond_emb.weight = nn.Parameter(torch.empty(planes, in_planes).uniform_(-b, b), requires_grad=False)
+            self.cond_emb.bias = nn.Parameter(torch.empty(planes).uniform_(-b, b), requires_grad=False)
+
+    @torch.no_grad()
+    def _run(self, x, cond):
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise LnsError("HIP device fp32 tensors only (no CPU fallback)")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        keep = [_host(self.fourier.weights1), _host(self.fourier.weights2), _host(self.conv.weight), _host(self.conv.bias)]
+        args = [k[1] for k in keep]
+        cptr = None
+        extra = [None, None, None, None]
+        if cond is not None:
+            cond = cond.to(torch.float32).contiguous()
+            cptr = ctypes.c_void_p(cond.data_ptr())
+            k2 = [_host(self.fourier.cond_emb.weights), _host(self.fourier.cond_emb.bias), _host(self.cond_emb.weight),
+                  _host(self.cond_emb.bias)]
+            keep += k2
+            extra = [k[1] for k in k2]
+        rc = _lib.lib().lns_op_fourier_block(ctypes.c_void_p(x.data_ptr()), B, C, H, W, self.modes[0], self.modes[1],
+                                             args[0], args[1], args[2], args[3], cptr, extra[0], extra[1], extra[2],
+                                             extra[3], ctypes.c_void_p(y.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise LnsError("lns_op_fourier_block failed (%d)" % rc)
+        return y
+
+
+class FourierBasicBlock(_FourierBase):
+    def __init__(self, in_planes, planes, modes, activation="gelu", residual=True):
+        if activation != "gelu":
+            raise NotImplementedError("gelu only (the reference's default and only use)")
+        super().__init__(in_planes, planes, modes, residual, conditional=False)
+
+    def forward(self, x):
+        return self._run(x, None)
+
+
+class CondFourierBasicBlock(_FourierBase):
+    def __init__(self, in_planes, planes, modes, residual=True):
+        super().__init__(in_planes, planes, modes, residual, conditional=True)
+
+    def forward(self, x, cond_emb):
+        return self._run(x, cond_emb)

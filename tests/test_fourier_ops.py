@@ -1,0 +1,62 @@
+"""Standalone FourierBasicBlock / CondFourierBasicBlock: the oracle (CPU)
+and the HIP op (GPU) against outputs of the REAL reference blocks (tests/golden/ops_fourier.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, rel_l2
+
+
+def _load():
+    d = np.load(os.path.join(GOLDEN, "ops_fourier.npz"))
+    return json.loads(bytes(d["meta"]).decode()), d
+
+
+def _weights(keys, seed):
+    from lns_amd import filler
+    sd = {}
+    for ks in keys:
+        k, shp = str(ks).split(":")
+        sd[k] = filler.fill_tensor(k, tuple(int(v) for v in shp.split("x")), seed)
+    return sd
+
+
+def _inputs(m):
+    from lns_amd import filler
+    x = filler.normal("xop", (m["B"], m["C"], m["H"], m["W"]), m["input_seed"])
+    cond = filler.normal("cop", (m["B"], m["C"]), m["input_seed"])
+    return x, cond
+
+
+def test_oracle_fourier_blocks_match_reference():
+    import lns_oracle
+    m, d = _load()
+    x, cond = _inputs(m)
+    sd = {"blk." + k: v for k, v in _weights(d["fourier_keys"], m["weight_seed"]).items()}
+    net = lns_oracle._Net(sd, (0, 0))
+    assert rel_l2(lns_oracle.fourier_basic_block(net, x, "blk"), d["fourier_y"]) < 2e-6
+    sd = {"blk." + k: v for k, v in _weights(d["cond_fourier_keys"], m["weight_seed"]).items()}
+    assert rel_l2(lns_oracle.cond_fourier_basic_block(sd, "blk", x, cond), d["cond_fourier_y"]) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conditional", [False, True])
+def test_hip_fourier_blocks_match_reference(conditional):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from lns_amd.modules.fourier_cond import CondFourierBasicBlock, FourierBasicBlock
+    m, d = _load()
+    x, cond = _inputs(m)
+    name = "cond_fourier" if conditional else "fourier"
+    blk = (CondFourierBasicBlock if conditional else FourierBasicBlock)(m["C"], m["C"], [m["m1"], m["m2"]])
+    w = _weights(d[name + "_keys"], m["weight_seed"])
+    assert set(blk.state_dict()) == set(w)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    xd = torch.from_numpy(x).cuda()
+    y = blk(xd, torch.from_numpy(cond).cuda()) if conditional else blk(xd)
+    y = y.cpu().numpy()
+    assert rel_l2(y, d[name + "_y"]) < 5e-6
+    assert rel_l2(y, d[name + "_y_f64"]) < 5e-6

@@ -141,5 +141,38 @@ def main(which):
         json.dump(man, f, indent=0, sort_keys=False)
 
 
+def make_op_goldens():
+    """Standalone Fourier blocks (not reached by any model config): outputs of the
+    reference's FourierBasicBlock / CondFourierBasicBlock on filler weights."""
+    import ref_shim
+    mods = ref_shim.load_reference()
+    out = {}
+    B, C, H, W, m1, m2 = 2, 8, 16, 24, 3, 5
+    x = filler.normal("xop", (B, C, H, W), INPUT_SEED)
+    cond = filler.normal("cop", (B, C), INPUT_SEED)
+    for name, blk, extra in (
+            ("fourier", mods["modules.basics"].FourierBasicBlock(C, C, modes=[m1, m2]), ()),
+            ("cond_fourier", mods["modules.fourier_cond"].CondFourierBasicBlock(C, C, modes=[m1, m2]),
+             (torch.from_numpy(cond),))):
+        filler.load_into_torch_module(blk, WEIGHT_SEED)
+        blk.eval()
+        with torch.no_grad():
+            y = blk(torch.from_numpy(x), *extra).numpy()
+            y64 = blk.double()(torch.from_numpy(x).double(), *[e.double() for e in extra]).numpy()
+        out[name + "_y"] = y.astype(np.float32)
+        out[name + "_y_f64"] = y64.astype(np.float32)
+        out[name + "_keys"] = np.array(sorted("%s:%s" % (k, "x".join(map(str, v.shape)))
+                                              for k, v in blk.state_dict().items()))
+    meta = dict(B=B, C=C, H=H, W=W, m1=m1, m2=m2, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "ops_fourier.npz"), **out)
+    print("ops_fourier written")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:] or list(CASES))
+    which = sys.argv[1:] or list(CASES) + ["ops"]
+    if "ops" in which:
+        which.remove("ops")
+        make_op_goldens()
+    if which:
+        main(which)

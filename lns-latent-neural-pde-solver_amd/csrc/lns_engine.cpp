@@ -96,7 +96,7 @@ static void pack_conv_weight(float* dst, const float* src, int cout_off, int cou
                 dst[((size_t)t * Cin_pad + ci) * Cout_pad + cout_off + co] = src[((size_t)co * cin + ci) * taps + t];
 }
 
-struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Hout, Wout, kc_log2; };
+struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Hout, Wout, kc_log2, sel_kc_log2; };
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
                           int kc_log2_pack, int Cout_pad, int force_variant) {
@@ -118,7 +118,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         ConvArgs tmp;
         memset(&tmp, 0, sizeof tmp);
         tmp.ks = k; tmp.kc_log2 = g.kc_log2; tmp.Cin_pad = 1 << kc_log2_pack;
-        int best_bw = -1, txn = 0, tyn = 0;
+        int best_bw = -1, txn = 0, tyn = 0, best_kc = g.kc_log2;
         if (k == 1) {
             // 1x1: the image is a flat array of H*W pixels, a tile is TN consecutive pixels
             if (stride != 1 || pad[0] || pad[1] || pad[2] || pad[3]) return false;
@@ -137,8 +137,9 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
                 const long cost = (long)((g.Hout + BH - 1) / BH) * BH * ((g.Wout + BW - 1) / BW) * BW;
                 tmp.PH = (BH - 1) * stride + (k - 1) * dil + 1;
                 tmp.PW = (BW - 1) * stride + (k - 1) * dil + 1;
-                if (!conv_fits(cands[ci], tmp)) continue;
-                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bw = lb; }
+                tmp.kc_log2 = g.kc_log2;
+                if (!conv_fits(cands[ci], tmp)) { tmp.kc_log2 = 2; if (!conv_fits(cands[ci], tmp)) continue; }
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bw = lb; best_kc = tmp.kc_log2; }
             }
             if (best_bw < 0) continue;
             const int BW = 1 << best_bw, BH = vi.TN / BW;
@@ -149,7 +150,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         const long blocks = (long)B * txn * tyn * ((Cout + vi.TM - 1) / vi.TM);
         g.variant = cands[ci]; g.bw_log2 = best_bw; g.tiles_x = txn; g.tiles_y = tyn;
         g.cout_tiles = (Cout + vi.TM - 1) / vi.TM;
-        g.PH = tmp.PH; g.PW = tmp.PW;
+        g.PH = tmp.PH; g.PW = tmp.PW; g.sel_kc_log2 = best_kc;
         found = true;
         if (blocks >= 512) break;
     }
@@ -326,7 +327,7 @@ struct Planner {
         if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
-        a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.kc_log2;
+        a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.sel_kc_log2;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
         a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
@@ -1274,7 +1275,7 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
-    a.kc_log2 = g.kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
+    a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
     a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
     hipStream_t s = static_cast<hipStream_t>(stream);

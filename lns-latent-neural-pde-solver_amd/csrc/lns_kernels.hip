@@ -10,6 +10,9 @@
 //   A operand (32 x 2):  lane holds A[row l31][k = kh]
 //   B operand (2 x 32):  lane holds B[k = kh][col l31]
 //   C/D (32 x 32, 16 regs): reg r of lane holds D[row (r&3) + 8*(r>>2) + 4*kh][col l31]
+#include <cstdlib>
+#include <type_traits>
+
 #include "lns_kernels.h"
 
 namespace lns {
@@ -56,28 +59,42 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 //   - K order: stage-major (KC fixed per kernel size, see conv_pick_kc_log2),
 //     tap-major inside a stage, channel pairs (k = 2*kk + kh).
 // ===========================================================================
-#define CONV_MAXE3 9    // 3x3: scalar patch elements per thread per stage
+#define CONV_MAXE3 9    // 3x3: scalar patch elements per thread per 4-channel stage
+#define CONV_MAXE3_K8 11 // 3x3: ... per 8-channel stage
 #define CONV_MAXE1 16   // 1x1: floats per thread per stage (4 x float4 when vectorised)
 #define CONV_MAXW 5     // weight float4 per thread per stage
 
 __device__ __forceinline__ float swish_f(float v) { return v / (1.0f + expf(-v)); }
+// prologue Swish inside the K loop: v_exp_f32 + v_rcp_f32 (~1 ulp each; worst-case relative error
+// of the result ~3e-7 for |v| <= 5, far below the accumulation noise of the following 576-term sums)
+__device__ __forceinline__ float swish_fast(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
-template <int MT, int NT, int WGM, int WGN, int KS, bool VEC>
+// KCL = channels per LDS stage (3x3: 4 or 8, 1x1: 16).  The MFMA loop always walks a stage in
+// sub-stages of KORD channels (3x3: 4, 1x1: 16), tap-major inside a sub-stage, so the fp32
+// accumulation ORDER of an output is the same for every KCL / tile variant / batch.
+template <int MT, int NT, int WGM, int WGN, int KS, bool VEC, int KCL>
 __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int TM = WGM * MT * 32;
     constexpr int TN = WGN * NT * 32;
     constexpr int V4 = TM / 4;
-    constexpr int MAXE = KS == 3 ? CONV_MAXE3 : CONV_MAXE1;
+    constexpr int KORD = KS == 3 ? 4 : 16;
+    constexpr int MAXE = KS == 3 ? (KCL == 8 ? CONV_MAXE3_K8 : CONV_MAXE3) : CONV_MAXE1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    constexpr int KC = KS == 3 ? 4 : 16;   // channels per stage: compile-time (see conv_pick_kc_log2)
-    constexpr int KC_LOG2 = KS == 3 ? 2 : 4;
+    constexpr int KC = KCL;
+    constexpr int KC_LOG2 = KCL == 4 ? 2 : (KCL == 8 ? 3 : 4);
     const int PH = a.PH, PW = a.PW;
     const int PLANE = KS == 3 ? PH * PW : TN;
-    const int xs_floats = (KC * PLANE + 3) & ~3;
-    const int ws_floats = KS * KS * KC * TM;
-    const int buf_floats = xs_floats + ws_floats;
+    constexpr int NW = (KS * KS * KCL * TM / 4 + NTHR - 1) / NTHR;   // weight float4 per thread per stage
+    // LDS stage buffers are sized by the per-thread slot counts, so every slot is written
+    // unconditionally (no per-element branches in the K loop)
+    constexpr int xs_floats = MAXE * NTHR;
+    constexpr int ws_floats = NW * NTHR * 4;
+    constexpr int buf_floats = xs_floats + ws_floats;
     float* lds = reinterpret_cast<float*>(smem);           // 2 x [Xs | Ws]
     float* ssl = lds + 2 * buf_floats;                     // [Cin_pad][2] scale/shift of this sample
     int* rmap = reinterpret_cast<int*>(ssl + a.Cin_pad * 2);
@@ -99,11 +116,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     const int HWin = a.Hin * a.Win;
     const float* xb = a.x + (long)b * a.x_bs;
     const bool has_ss = a.ss != nullptr;
-    const bool has_act = a.act_in == ACT_SWISH;
+    const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;   // prologue: none / scale-shift / + Swish
 
-    if (has_ss)
-        for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
-            ssl[i] = (i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : 0.0f;
+    for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
+        ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
     if (KS == 3) {
         for (int i = tid; i < PH; i += NTHR) rmap[i] = a.rowmap[ty * BH * a.stride + i];
         for (int i = tid; i < PW; i += NTHR) cmap[i] = a.colmap[tx * BW * a.stride + i];
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     // ---- per-thread patch descriptors (the same in every stage) ----------------
     // 3x3   : source offset inside a stage (-1 = zero) | channel-in-stage << 24, one per element
     // 1x1   : one descriptor per 4 consecutive pixels (VEC) or per pixel
-    constexpr int NDESC = KS == 3 ? CONV_MAXE3 : (VEC ? CONV_MAXE1 / 4 : CONV_MAXE1);
+    constexpr int NDESC = KS == 3 ? MAXE : (VEC ? CONV_MAXE1 / 4 : CONV_MAXE1);
     int pdesc[NDESC];
     const int p0 = tx * TN;   // 1x1: first flat pixel of this tile
     if (KS == 3) {
@@ -145,13 +161,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     }
     // per-thread weight slab descriptors (float offset of the stage-0 source)
     const int nw4 = KS * KS * KC * V4;
-    int wdesc[CONV_MAXW];
+    int wdesc[NW];
 #pragma unroll
-    for (int i = 0; i < CONV_MAXW; ++i) {
+    for (int i = 0; i < NW; ++i) {
         const int fi = tid + i * NTHR;
         const int row = fi / V4, c4 = fi - row * V4;
         const int tap = row >> KC_LOG2, k = row & (KC - 1);
-        wdesc[i] = (fi < nw4) ? ((tap * a.Cin_pad + k) * a.Cout_pad + ct * TM + c4 * 4) : -1;
+        wdesc[i] = (fi < nw4) ? ((tap * a.Cin_pad + k) * a.Cout_pad + ct * TM + c4 * 4) : 0;   // clamped: slot unused
     }
 
     int boff[NT];
@@ -170,72 +186,104 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
     float pv[MAXE];
-    float wv[CONV_MAXW][4];
+    float wv[NW][4];
 
-    auto issue_loads = [&](int c0) __attribute__((always_inline)) {
-        const float* xc = xb + (long)c0 * HWin;
+    // TAIL = the stage reaches past Cin (only when Cin % KC != 0): per-element channel checks and a
+    // safe address for masked elements.  Otherwise every element is `scalar stage base + 32-bit
+    // per-lane offset` (masked elements have offset 0 and are zeroed at write time): one
+    // instruction per load, no address arithmetic, no branches.
+    auto issue_loads_t = [&](auto tail_tag, int c0) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const char* xc = reinterpret_cast<const char*>(xb + (long)c0 * HWin);
 #pragma unroll
         for (int j = 0; j < NDESC; ++j) {
             const int d = pdesc[j];
-            const bool ok = d >= 0 && (c0 + (d >> 24)) < a.Cin;
-            // loads are unconditional (no branches); masked elements read the sample's first
-            // floats instead (always in bounds, 16-byte aligned) and are zeroed by the select
-            const float* src = ok ? xc + (d & 0xFFFFFF) : xb;
-            if (KS == 1 && VEC) {
-                const float4 t = *reinterpret_cast<const float4*>(src);
-                pv[4 * j + 0] = ok ? t.x : 0.0f; pv[4 * j + 1] = ok ? t.y : 0.0f;
-                pv[4 * j + 2] = ok ? t.z : 0.0f; pv[4 * j + 3] = ok ? t.w : 0.0f;
+            unsigned off = d >= 0 ? ((unsigned)(d & 0xFFFFFF) << 2) : 0u;
+            const char* base = xc;
+            if (TAIL) {
+                const bool ok = d >= 0 && (c0 + (d >> 24)) < a.Cin;
+                if (!ok) { off = 0u; base = reinterpret_cast<const char*>(xb); }
+                const float* src = reinterpret_cast<const float*>(ok ? xc + off : reinterpret_cast<const char*>(xb));
+                if (KS == 1 && VEC) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    pv[4 * j + 0] = t.x; pv[4 * j + 1] = t.y; pv[4 * j + 2] = t.z; pv[4 * j + 3] = t.w;
+                } else {
+                    pv[j] = *src;
+                }
+            } else if (KS == 1 && VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(base + off);
+                pv[4 * j + 0] = t.x; pv[4 * j + 1] = t.y; pv[4 * j + 2] = t.z; pv[4 * j + 3] = t.w;
             } else {
-                const float t = *src;
-                pv[j] = ok ? t : 0.0f;
+                pv[j] = *reinterpret_cast<const float*>(base + off);
             }
         }
         const float* wc = a.w + (long)c0 * a.Cout_pad;
 #pragma unroll
-        for (int i = 0; i < CONV_MAXW; ++i) {
-            if (KS == 1 && i >= 2) break;                   // 1x1: at most 16*128/4/256 = 2 float4
-            const float4 t = *reinterpret_cast<const float4*>(wc + (wdesc[i] < 0 ? 0 : wdesc[i]));
+        for (int i = 0; i < NW; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(wc + wdesc[i]);
             wv[i][0] = t.x; wv[i][1] = t.y; wv[i][2] = t.z; wv[i][3] = t.w;
         }
     };
-    auto xform = [&](float v, int c) __attribute__((always_inline)) -> float {
-        if (has_ss) v = v * ssl[2 * c] + ssl[2 * c + 1];
-        if (has_act) v = swish_f(v);
-        return v;
+    auto issue_loads = [&](int c0) __attribute__((always_inline)) {
+        if (c0 + KC > a.Cin) issue_loads_t(std::true_type{}, c0);
+        else issue_loads_t(std::false_type{}, c0);
     };
-    auto write_lds = [&](int c0, float* Xs, float* Ws) __attribute__((always_inline)) {
+    // MODE is compile-time inside (selected by one uniform branch per stage): branch-free per element
+    auto write_lds_m = [&](auto mode_tag, int c0, float* Xs, float* Ws) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
         for (int j = 0; j < NDESC; ++j) {
             const int d = pdesc[j];
-            const int c = c0 + (d >> 24);
+            const int c = c0 + ((d >> 24) & 63);
             const bool ok = d >= 0 && c < a.Cin;
+            float2 st = make_float2(1.0f, 0.0f);
+            if (MODE >= 1) st = *reinterpret_cast<const float2*>(ssl + 2 * (c < a.Cin_pad ? c : 0));
             if (KS == 1 && VEC) {
-                const int idx = tid + j * NTHR;
-                if (idx < KC * (TN / 4)) {
-                    float4 t = make_float4(pv[4 * j], pv[4 * j + 1], pv[4 * j + 2], pv[4 * j + 3]);
-                    if (ok && (has_ss || has_act)) { t.x = xform(t.x, c); t.y = xform(t.y, c); t.z = xform(t.z, c); t.w = xform(t.w, c); }
-                    *reinterpret_cast<float4*>(Xs + idx * 4) = t;
+                float4 t;
+                float* tp = &t.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = pv[4 * j + q];
+                    if (MODE >= 1) v = v * st.x + st.y;
+                    if (MODE == 2) v = swish_fast(v);
+                    tp[q] = ok ? v : 0.0f;
                 }
+                *reinterpret_cast<float4*>(Xs + (tid + j * NTHR) * 4) = t;
             } else {
-                const int idx = tid + j * NTHR;
-                if (idx < KC * PLANE) {
-                    float v = pv[j];
-                    if (ok && (has_ss || has_act)) v = xform(v, c);
-                    Xs[idx] = v;
-                }
+                float v = pv[j];
+                if (MODE >= 1) v = v * st.x + st.y;
+                if (MODE == 2) v = swish_fast(v);
+                Xs[tid + j * NTHR] = ok ? v : 0.0f;
             }
         }
 #pragma unroll
-        for (int i = 0; i < CONV_MAXW; ++i) {
-            if (KS == 1 && i >= 2) break;
-            if (wdesc[i] >= 0)
-                *reinterpret_cast<float4*>(Ws + (tid + i * NTHR) * 4) = make_float4(wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
-        }
+        for (int i = 0; i < NW; ++i)
+            *reinterpret_cast<float4*>(Ws + (tid + i * NTHR) * 4) = make_float4(wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
+    };
+    auto write_lds = [&](int c0, float* Xs, float* Ws) __attribute__((always_inline)) {
+        if (pro_mode == 2) write_lds_m(std::integral_constant<int, 2>{}, c0, Xs, Ws);
+        else if (pro_mode == 1) write_lds_m(std::integral_constant<int, 1>{}, c0, Xs, Ws);
+        else write_lds_m(std::integral_constant<int, 0>{}, c0, Xs, Ws);
     };
 
     int toff[KS * KS];
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t) toff[t] = KS == 3 ? ((t / 3) * a.dil) * PW + (t % 3) * a.dil : 0;
+
+    // MFMA steps of one stage, in accumulation order: sub-stage (KORD channels) > tap > channel pair
+    constexpr int NSUB = KCL / KORD, NKK = KORD / 2, NSTEP = NSUB * KS * KS * NKK;
+    auto load_ops = [&](int s, const float* wbase, const float* xbase, float (&av)[MT], float (&bv)[NT])
+                        __attribute__((always_inline)) {
+        const int sub = s / (KS * KS * NKK), rem = s - sub * (KS * KS * NKK);
+        const int t = rem / NKK, kk = rem - t * NKK;
+        const int k0 = sub * KORD + 2 * kk;
+        const float* wsp = wbase + (t * KC + k0) * TM;
+        const float* xsp = xbase + k0 * PLANE + toff[t];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = wsp[mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = xsp[boff[nt]];
+    };
 
     issue_loads(0);
     int buf = 0;
@@ -248,26 +296,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 
         const float* wbase = Ws + wm * (MT * 32) + l31 + kh * TM;
         const float* xbase = Xs + kh * PLANE;
+        // operands of step s+1 are fetched from LDS while the MFMAs of step s execute
+        float av[2][MT], bv[2][NT];
+        load_ops(0, wbase, xbase, av[0], bv[0]);
 #pragma unroll
-        for (int t = 0; t < KS * KS; ++t) {
-            const float* wsp = wbase + t * KC * TM;
-            const float* xsp = xbase + toff[t];
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) load_ops(s + 1, wbase, xbase, av[(s + 1) & 1], bv[(s + 1) & 1]);
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                float av[MT], bv[NT];
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = wsp[(2 * kk) * TM + mt * 32];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = xsp[(2 * kk) * PLANE + boff[nt]];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-            }
-            // keep the scheduler from hoisting every tap's LDS reads to the top of the stage
-            // (register blow-up); one tap of look-ahead is plenty at 64 cycles per MFMA
-            if (KS == 3) __builtin_amdgcn_sched_barrier(0);
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt], bv[s & 1][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep the one-step look-ahead (bounds register pressure)
         }
         buf ^= 1;
     }
@@ -276,18 +316,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     const int HWo = a.Hout * a.Wout;
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+    const bool full_co = (ct + 1) * TM <= a.Cout;   // no cout masking needed in this block
+    if (a.bias || a.badd) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int cob = ct * TM + (wm * MT + mt) * 32 + 4 * kh;
-        if (a.bias || a.badd) {
+        for (int mt = 0; mt < MT; ++mt) {
+            const int cob = ct * TM + (wm * MT + mt) * 32 + 4 * kh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cob + (r & 3) + 8 * (r >> 2);
+                const int cc = co < a.Cout ? co : 0;
                 float add = 0.0f;
-                if (co < a.Cout) {
-                    if (a.bias) add += a.bias[co];
-                    if (a.badd) add += a.badd[(long)b * a.Cout + co];
-                }
+                if (a.bias) add += a.bias[cc];
+                if (a.badd) add += a.badd[(long)b * a.Cout + cc];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
             }
@@ -308,6 +348,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
     }
+    // stores: row r of a tile is cout cob + (r&3) + 8*(r>>2); 128-byte pixel runs per half-wave.
+    // Offsets from one per-(mt,nt) base pointer are multiples of HWo (uniform scalars).
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
@@ -316,17 +358,33 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
         else { oy = 0; ox = p0 + p; }
         const bool pvld = KS == 3 ? ((oy < a.Hout) && (ox < a.Wout)) : (ox < HWo);
         const int pix = oy * a.Wout + ox;
+        if (!pvld) continue;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int cob = ct * TM + (wm * MT + mt) * 32 + 4 * kh;
+            float* yp = yb + ((long)cob * HWo + pix);
+            if (full_co) {
+                if (rb) {
+                    const float* rp = rb + ((long)cob * HWo + pix);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cob + (r & 3) + 8 * (r >> 2);
-                if (pvld && co < a.Cout) {
-                    const int o = co * HWo + pix;
-                    float v = acc[mt][nt][r];
-                    if (rb) v += rb[o];
-                    yb[o] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = ((r & 3) + 8 * (r >> 2)) * HWo;
+                        yp[ro] = acc[mt][nt][r] + rp[ro];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yp[((r & 3) + 8 * (r >> 2)) * HWo] = acc[mt][nt][r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cob + (r & 3) + 8 * (r >> 2);
+                    if (co < a.Cout) {
+                        const int ro = ((r & 3) + 8 * (r >> 2)) * HWo;
+                        float v = acc[mt][nt][r];
+                        if (rb) v += rb[(long)cob * HWo + pix + ro];
+                        yp[ro] = v;
+                    }
                 }
             }
         }
@@ -344,25 +402,27 @@ ConvVariantInfo conv_variant_info(int v) { return kConvInfo[v]; }
 // so a trajectory's result is bit-identical whatever batch (or GPU shard) it is computed in.
 int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
     (void)stride;
-    int lg = ks == 3 ? 2 : 4;     // must match the KC constants compiled into conv_mfma_kernel
+    static const bool k4 = getenv("LNS_CONV_KCL4") != nullptr;   // tuning knob
+    int lg = ks == 3 ? (k4 ? 2 : 3) : 4;     // preferred LDS stage depth; conv_fits() may fall back to 4 for 3x3
     return lg < kc_log2_max ? lg : kc_log2_max;
 }
 
+static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8 : CONV_MAXE3) : CONV_MAXE1; }
+
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
     const int KC = 1 << a.kc_log2;
-    const int TM = kConvInfo[variant].TM, TN = kConvInfo[variant].TN;
-    size_t xs = ((size_t)KC * (a.ks == 3 ? a.PH * a.PW : TN) + 3) & ~(size_t)3;
-    size_t ws = (size_t)a.ks * a.ks * KC * TM;
+    const int TM = kConvInfo[variant].TM;
+    const size_t xs = (size_t)conv_maxe(a.ks, KC) * 256;
+    const size_t ws = (size_t)(((size_t)a.ks * a.ks * KC * TM / 4 + 255) / 256) * 256 * 4;
     return (2 * (xs + ws) + (size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
 }
 
 bool conv_fits(int variant, const ConvArgs& a) {
     const long KC = 1 << a.kc_log2;
-    const int TM = kConvInfo[variant].TM, TN = kConvInfo[variant].TN;
-    if (KC != (a.ks == 3 ? 4 : 16)) return false;
-    if (conv_lds_bytes(variant, a) > 150 * 1024 || (a.Cin_pad % KC) != 0) return false;
-    if ((long)a.ks * a.ks * KC * TM > (long)(a.ks == 3 ? CONV_MAXW : 2) * 1024) return false;
-    if (a.ks == 3) return KC * a.PH * a.PW <= (long)CONV_MAXE3 * 256;
+    const int TN = kConvInfo[variant].TN;
+    if (a.ks == 3 ? (KC != 4 && KC != 8) : (KC != 16)) return false;
+    if (conv_lds_bytes(variant, a) > (KC == 8 ? 72 : 150) * 1024 || (a.Cin_pad % KC) != 0) return false;
+    if (a.ks == 3) return KC * a.PH * a.PW <= (long)conv_maxe(3, (int)KC) * 256;
     return KC * TN <= (long)CONV_MAXE1 * 256;
 }
 
@@ -370,9 +430,10 @@ template <int MT, int NT, int WGM, int WGN>
 static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
     dim3 blk(64 * WGM * WGN);
-    if (a.ks == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false>), grid, blk, lds, s, a);
-    else if (a.vec4) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, true>), grid, blk, lds, s, a);
-    else hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, false>), grid, blk, lds, s, a);
+    if (a.ks == 3 && a.kc_log2 == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false, 8>), grid, blk, lds, s, a);
+    else if (a.ks == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false, 4>), grid, blk, lds, s, a);
+    else if (a.vec4) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, true, 16>), grid, blk, lds, s, a);
+    else hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, false, 16>), grid, blk, lds, s, a);
     return hipGetLastError();
 }
 
@@ -1204,24 +1265,30 @@ hipError_t init_kernels() {
 #define LNS_SET_LDS(k)                                                                            \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
-    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, true>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, false>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, true>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, false>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 3, false>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, true>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, false>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, true>))
-    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, false>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 3, false>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 1, true>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 1, false>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 3, false>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, true>))
-    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, false>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false, 8>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, true, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, false, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false, 8>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, true, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, false, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 3, false, 8>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, true, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, false, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false, 8>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, true, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, false, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 3, false, 8>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 1, true, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 2, 2, 1, false, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 3, false, 8>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, true, 16>))
+    LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, false, 16>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))

@@ -188,52 +188,33 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     float pv[MAXE];
     float wv[NW][4];
 
-    // TAIL = the stage reaches past Cin (only when Cin % KC != 0): per-element channel checks and a
-    // safe address for masked elements.  Otherwise every element is `scalar stage base + 32-bit
-    // per-lane offset` (masked elements have offset 0 and are zeroed at write time): one
-    // instruction per load, no address arithmetic, no branches.
-    auto issue_loads_t = [&](auto tail_tag, int c0) __attribute__((always_inline)) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        const char* xc = reinterpret_cast<const char*>(xb + (long)c0 * HWin);
-#pragma unroll
-        for (int j = 0; j < NDESC; ++j) {
-            const int d = pdesc[j];
-            unsigned off = d >= 0 ? ((unsigned)(d & 0xFFFFFF) << 2) : 0u;
-            const char* base = xc;
-            if (TAIL) {
-                const bool ok = d >= 0 && (c0 + (d >> 24)) < a.Cin;
-                if (!ok) { off = 0u; base = reinterpret_cast<const char*>(xb); }
-                const float* src = reinterpret_cast<const float*>(ok ? xc + off : reinterpret_cast<const char*>(xb));
-                if (KS == 1 && VEC) {
-                    const float4 t = *reinterpret_cast<const float4*>(src);
-                    pv[4 * j + 0] = t.x; pv[4 * j + 1] = t.y; pv[4 * j + 2] = t.z; pv[4 * j + 3] = t.w;
-                } else {
-                    pv[j] = *src;
-                }
-            } else if (KS == 1 && VEC) {
-                const float4 t = *reinterpret_cast<const float4*>(base + off);
-                pv[4 * j + 0] = t.x; pv[4 * j + 1] = t.y; pv[4 * j + 2] = t.z; pv[4 * j + 3] = t.w;
+    // ---- staging slots ---------------------------------------------------------
+    // slot q < NDESC : patch descriptor q ; slot NDESC + i : weight float4 i.
+    // load_slot : global -> registers (unconditional; masked elements read the sample's first
+    //             floats, always in bounds, and are zeroed at write time)
+    // write_slot: registers -> LDS with the prologue transform (MODE: 0 none, 1 scale/shift,
+    //             2 scale/shift + Swish); every slot is written, so no branches.
+    auto load_slot = [&](int q, int c0) __attribute__((always_inline)) {
+        if (q < NDESC) {
+            const int d = pdesc[q];
+            const bool ok = d >= 0 && (c0 + (d >> 24)) < a.Cin;
+            const float* src = ok ? xb + ((long)c0 * HWin + (d & 0xFFFFFF)) : xb;
+            if (KS == 1 && VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                pv[4 * q + 0] = t.x; pv[4 * q + 1] = t.y; pv[4 * q + 2] = t.z; pv[4 * q + 3] = t.w;
             } else {
-                pv[j] = *reinterpret_cast<const float*>(base + off);
+                pv[q] = *src;
             }
-        }
-        const float* wc = a.w + (long)c0 * a.Cout_pad;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(wc + wdesc[i]);
+        } else {
+            const int i = q - NDESC;
+            const float4 t = *reinterpret_cast<const float4*>(a.w + ((long)c0 * a.Cout_pad + wdesc[i]));
             wv[i][0] = t.x; wv[i][1] = t.y; wv[i][2] = t.z; wv[i][3] = t.w;
         }
     };
-    auto issue_loads = [&](int c0) __attribute__((always_inline)) {
-        if (c0 + KC > a.Cin) issue_loads_t(std::true_type{}, c0);
-        else issue_loads_t(std::false_type{}, c0);
-    };
-    // MODE is compile-time inside (selected by one uniform branch per stage): branch-free per element
-    auto write_lds_m = [&](auto mode_tag, int c0, float* Xs, float* Ws) __attribute__((always_inline)) {
+    auto write_slot = [&](auto mode_tag, int q, int c0, float* Xs, float* Ws) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
-#pragma unroll
-        for (int j = 0; j < NDESC; ++j) {
-            const int d = pdesc[j];
+        if (q < NDESC) {
+            const int d = pdesc[q];
             const int c = c0 + ((d >> 24) & 63);
             const bool ok = d >= 0 && c < a.Cin;
             float2 st = make_float2(1.0f, 0.0f);
@@ -242,28 +223,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
                 float4 t;
                 float* tp = &t.x;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = pv[4 * j + q];
+                for (int u = 0; u < 4; ++u) {
+                    float v = pv[4 * q + u];
                     if (MODE >= 1) v = v * st.x + st.y;
                     if (MODE == 2) v = swish_fast(v);
-                    tp[q] = ok ? v : 0.0f;
+                    tp[u] = ok ? v : 0.0f;
                 }
-                *reinterpret_cast<float4*>(Xs + (tid + j * NTHR) * 4) = t;
+                *reinterpret_cast<float4*>(Xs + (tid + q * NTHR) * 4) = t;
             } else {
-                float v = pv[j];
+                float v = pv[q];
                 if (MODE >= 1) v = v * st.x + st.y;
                 if (MODE == 2) v = swish_fast(v);
-                Xs[tid + j * NTHR] = ok ? v : 0.0f;
+                Xs[tid + q * NTHR] = ok ? v : 0.0f;
             }
-        }
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
+        } else {
+            const int i = q - NDESC;
             *reinterpret_cast<float4*>(Ws + (tid + i * NTHR) * 4) = make_float4(wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
-    };
-    auto write_lds = [&](int c0, float* Xs, float* Ws) __attribute__((always_inline)) {
-        if (pro_mode == 2) write_lds_m(std::integral_constant<int, 2>{}, c0, Xs, Ws);
-        else if (pro_mode == 1) write_lds_m(std::integral_constant<int, 1>{}, c0, Xs, Ws);
-        else write_lds_m(std::integral_constant<int, 0>{}, c0, Xs, Ws);
+        }
     };
 
     int toff[KS * KS];
@@ -272,6 +248,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 
     // MFMA steps of one stage, in accumulation order: sub-stage (KORD channels) > tap > channel pair
     constexpr int NSUB = KCL / KORD, NKK = KORD / 2, NSTEP = NSUB * KS * KS * NKK;
+    constexpr int NSLOT = NDESC + NW;
+    constexpr int SPS = (NSLOT + NSTEP - 1) / NSTEP;      // staging slots handled per MFMA step
     auto load_ops = [&](int s, const float* wbase, const float* xbase, float (&av)[MT], float (&bv)[NT])
                         __attribute__((always_inline)) {
         const int sub = s / (KS * KS * NKK), rem = s - sub * (KS * KS * NKK);
@@ -285,32 +263,58 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
         for (int nt = 0; nt < NT; ++nt) bv[nt] = xsp[boff[nt]];
     };
 
-    issue_loads(0);
-    int buf = 0;
-    for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
-        float* Xs = lds + buf * buf_floats;
-        float* Ws = Xs + xs_floats;
-        write_lds(c0, Xs, Ws);
+    // One K loop per prologue mode (the mode is block-uniform): while the MFMAs of stage c run
+    // from LDS buffer c&1, the SAME instruction stream (a) transforms and writes the registers
+    // holding stage c+1 into the other buffer and (b) re-fills each register, as soon as it is
+    // free, with stage c+2 from global memory.  Staging is spread over the MFMA steps, so the
+    // matrix pipe is not idle while a wave stages; one barrier per stage.
+    auto k_loop = [&](auto mode_tag) __attribute__((always_inline)) {
+        const int last = a.Cin_pad - KC;
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) load_slot(q, 0);
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) write_slot(mode_tag, q, 0, lds, lds + xs_floats);
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) load_slot(q, KC < last ? KC : last);
         __syncthreads();
-        if (c0 + KC < a.Cin_pad) issue_loads(c0 + KC);   // in flight during the MFMAs below
-
-        const float* wbase = Ws + wm * (MT * 32) + l31 + kh * TM;
-        const float* xbase = Xs + kh * PLANE;
-        // operands of step s+1 are fetched from LDS while the MFMAs of step s execute
-        float av[2][MT], bv[2][NT];
-        load_ops(0, wbase, xbase, av[0], bv[0]);
+        int buf = 0;
+        for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
+            const float* Xs = lds + buf * buf_floats;
+            const float* Ws = Xs + xs_floats;
+            float* Xn = lds + (buf ^ 1) * buf_floats;
+            float* Wn = Xn + xs_floats;
+            // past the end the staging repeats the last stage into the idle buffer (harmless, branch-free)
+            const int cw = c0 + KC < last ? c0 + KC : last;
+            const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
+            const float* wbase = Ws + wm * (MT * 32) + l31 + kh * TM;
+            const float* xbase = Xs + kh * PLANE;
+            float av[2][MT], bv[2][NT];
+            load_ops(0, wbase, xbase, av[0], bv[0]);
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) load_ops(s + 1, wbase, xbase, av[(s + 1) & 1], bv[(s + 1) & 1]);
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + 1 < NSTEP) load_ops(s + 1, wbase, xbase, av[(s + 1) & 1], bv[(s + 1) & 1]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt], bv[s & 1][nt], acc[mt][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // keep the one-step look-ahead (bounds register pressure)
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt], bv[s & 1][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < SPS; ++u) {
+                    const int q = s * SPS + u;
+                    if (q < NSLOT) {
+                        write_slot(mode_tag, q, cw, Xn, Wn);
+                        load_slot(q, cl2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // pin the interleave (and bound register pressure)
+            }
+            __syncthreads();
+            buf ^= 1;
         }
-        buf ^= 1;
-    }
+    };
+    if (pro_mode == 2) k_loop(std::integral_constant<int, 2>{});
+    else if (pro_mode == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
 
     // ---- epilogue ---------------------------------------------------------------
     const int HWo = a.Hout * a.Wout;

@@ -278,7 +278,8 @@ struct Planner {
         op.gn.groups = groups; op.gn.eps = eps;
         op.gn.gamma = as_ptr<const float>(vecp(vg)); op.gn.beta = as_ptr<const float>(vecp(vb));
         op.gn.premul = as_ptr<const float>(premul);
-        x.ss_off = arena.alloc((size_t)B * x.C * 2 * 4);
+        // [B][C][2] scale/shift followed by [B][C][2] scratch of the two-stage path
+        x.ss_off = arena.alloc((size_t)B * x.C * 4 * 4);
         x.ss = tag(SP_WS, x.ss_off); x.ss_owned = true;
         op.gn.ss = as_ptr<float>(x.ss); op.gn.B = B;
         op.bytes = 2.0 * B * x.C * x.H * x.W * 4;
@@ -845,7 +846,7 @@ struct Runner {
                 case OP_GNSTATS: {
                     GnStatsArgs a = op.gn;
                     fix(a.x, B); fix(a.gamma, B); fix(a.beta, B); fix(a.premul, B); fix(a.ss, B); fixbs(a.x_bs, B);
-                    rc = launch_gn_stats(a, stream);
+                    rc = launch_gn_stats(a, a.ss + (size_t)a.B * a.C * 2, stream);
                     break;
                 }
                 case OP_LNPE: {
@@ -1298,8 +1299,11 @@ int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, flo
     a.x = x; a.x_bs = (long)C * HW; a.C = C; a.HW = HW; a.groups = groups; a.eps = eps;
     a.gamma = gamma_host ? dgb : nullptr; a.beta = beta_host ? dgb + C : nullptr; a.premul = premul; a.ss = ss; a.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    OPCHK(launch_gn_stats(a, s));
+    float* part = nullptr;
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&part), (size_t)B * C * 2 * 4));
+    OPCHK(launch_gn_stats(a, part, s));
     OPCHK(hipStreamSynchronize(s));
+    (void)hipFree(part);
     (void)hipFree(dgb);
     return LNS_OK;
 }

@@ -58,7 +58,9 @@ struct GnStatsArgs {
     float* ss;                               // [B][C][2]
     int B;
 };
-hipError_t launch_gn_stats(const GnStatsArgs& a, hipStream_t s);
+// part: [B][C][2] scratch enabling the two-stage path (may be null)
+bool gn_stats_two_stage(const GnStatsArgs& a);
+hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s);
 
 // LayerNorm over channels of a channel-major token tensor + positional embedding
 struct LnPeArgs {

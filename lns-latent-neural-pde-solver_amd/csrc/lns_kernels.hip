@@ -509,8 +509,82 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsArgs a) {
     }
 }
 
-hipError_t launch_gn_stats(const GnStatsArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a);
+// Two-stage variant for launches with few (sample, group) pairs (GroupNorm(1, C)): stage 1 gives
+// every (sample, channel) plane its own block (mean and centred second moment), stage 2 merges
+// the channels of a group with the pairwise update of Chan et al. -- exact two-pass numerics per
+// plane, parallelism B*C instead of B*groups.
+__global__ __launch_bounds__(256) void gn_partial_kernel(GnStatsArgs a, float* part) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* xs = a.x + (long)b * a.x_bs + (long)c * a.HW;
+    const int n = a.HW;
+    const bool v4 = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15) == 0);
+    float s = 0.0f;
+    if (v4) {
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        for (int i = threadIdx.x; i < (n >> 2); i += 256) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) s += xs[i];
+    }
+    const float mean = block_sum_256(s, red) / (float)n;
+    float q = 0.0f;
+    if (v4) {
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+            const float4 v = x4[i];
+            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) { const float d = xs[i] - mean; q += d * d; }
+    }
+    const float m2 = block_sum_256(q, red);
+    if (threadIdx.x == 0) { part[((long)b * a.C + c) * 2] = mean; part[((long)b * a.C + c) * 2 + 1] = m2; }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GnStatsArgs a, const float* part) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int cg = a.C / a.groups;
+    const float* pm = a.premul ? a.premul + (long)b * a.C + g * cg : nullptr;
+    const float n = (float)a.HW;
+    // statistics of x * premul: mean_c -> p mean_c, M2_c -> p^2 M2_c
+    float sm = 0.0f;
+    for (int c = lane; c < cg; c += 64) {
+        const float p = pm ? pm[c] : 1.0f;
+        sm += p * part[((long)b * a.C + g * cg + c) * 2];
+    }
+    const float mean = wave_sum(sm) / (float)cg;
+    float m2 = 0.0f;
+    for (int c = lane; c < cg; c += 64) {
+        const float p = pm ? pm[c] : 1.0f;
+        const float mc = p * part[((long)b * a.C + g * cg + c) * 2];
+        const float d = mc - mean;
+        m2 += p * p * part[((long)b * a.C + g * cg + c) * 2 + 1] + n * d * d;
+    }
+    const float var = wave_sum(m2) / (n * (float)cg);
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    for (int c = lane; c < cg; c += 64) {
+        const int ch = g * cg + c;
+        const float ga = a.gamma ? a.gamma[ch] : 1.0f;
+        const float be = a.beta ? a.beta[ch] : 0.0f;
+        const float p = pm ? pm[c] : 1.0f;
+        a.ss[((long)b * a.C + ch) * 2] = rstd * ga * p;
+        a.ss[((long)b * a.C + ch) * 2 + 1] = be - mean * rstd * ga;
+    }
+}
+
+bool gn_stats_two_stage(const GnStatsArgs& a) {
+    // depends on the layer only, never on the batch: results stay bit-identical across batch sizes
+    return a.C / a.groups >= 32;
+}
+
+hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s) {
+    if (part && gn_stats_two_stage(a)) {
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(a.C, a.B), dim3(256), 0, s, a, part);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, s, a, static_cast<const float*>(part));
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -519,21 +593,36 @@ hipError_t launch_gn_stats(const GnStatsArgs& a, hipStream_t s) {
 // one thread per token, channel loops are coalesced across the wave.
 // ===========================================================================
 __global__ __launch_bounds__(256) void ln_pe_kernel(LnPeArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // block = 64 tokens x 4 channel quarters: every load is a 256-byte run of tokens of one channel
+    __shared__ float red[4][64];
+    __shared__ float stat[2][64];
+    const int lane = threadIdx.x & 63, qd = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     const int b = blockIdx.y;
-    if (i >= a.n) return;
-    const float* xs = a.x + (long)b * a.x_bs + i;
+    const bool ok = i < a.n;
+    const int cq = (a.C + 3) / 4, c_lo = qd * cq, c_hi = min(a.C, c_lo + cq);
+    const float* xs = a.x + (long)b * a.x_bs + (ok ? i : 0);
     float s = 0.0f;
-    for (int c = 0; c < a.C; ++c) s += xs[(long)c * a.n];
-    const float mean = s / (float)a.C;
+    for (int c = c_lo; c < c_hi; ++c) s += xs[(long)c * a.n];
+    red[qd][lane] = s;
+    __syncthreads();
+    if (qd == 0) stat[0][lane] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)a.C;
+    __syncthreads();
+    const float mean = stat[0][lane];
     float q = 0.0f;
-    for (int c = 0; c < a.C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         const float d = xs[(long)c * a.n] - mean;
         q += d * d;
     }
-    const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+    red[qd][lane] = q;
+    __syncthreads();
+    if (qd == 0)
+        stat[1][lane] = 1.0f / sqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)a.C + a.eps);
+    __syncthreads();
+    const float rstd = stat[1][lane];
+    if (!ok) return;
     float* hs = a.h + (long)b * a.C * a.n + i;
-    for (int c = 0; c < a.C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         float v = (xs[(long)c * a.n] - mean) * rstd * a.gamma[c] + a.beta[c];
         if (a.pe_t) v += a.pe_t[(long)c * a.pe_stride + i];
         hs[(long)c * a.n] = v;
@@ -541,7 +630,7 @@ __global__ __launch_bounds__(256) void ln_pe_kernel(LnPeArgs a) {
 }
 
 hipError_t launch_ln_pe(const LnPeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(ln_pe_kernel, dim3((a.n + 255) / 256, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ln_pe_kernel, dim3((a.n + 63) / 64, a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -684,90 +773,69 @@ hipError_t launch_fa_pool(const FaPoolArgs& a, hipStream_t s) {
 // GELU -> Linear(+bias).  8 rows per block so every weight is read once per 8
 // rows; weights are stored in-major so lanes read consecutive outputs.
 // ===========================================================================
-#define FAR_ROWS 8
-__global__ __launch_bounds__(128) void fa_reducer_kernel(FaReducerArgs a) {
+#define FAR_ROWS 16
+__global__ __launch_bounds__(256) void fa_reducer_kernel(FaReducerArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = a.C, Hid = a.Hid, Out = a.Out;
-    float* vin = reinterpret_cast<float*>(smem);      // [R][C]
+    float* w_in = reinterpret_cast<float*>(smem);     // [C][C]   in-major
+    float* w1 = w_in + C * C;                         // [C][Hid]
+    float* w2 = w1 + C * Hid;                         // [Hid][Out]
+    float* vin = w2 + Hid * Out;                      // [R][C]
     float* t = vin + FAR_ROWS * C;                    // [R][C]
     float* hb = t + FAR_ROWS * C;                     // [R][Hid]
-    float* stat = hb + FAR_ROWS * Hid;                // [R][2]
-    const long row0 = (long)blockIdx.x * FAR_ROWS;
     const int tid = threadIdx.x;
-    for (int i = tid; i < FAR_ROWS * C; i += 128) {
+    // all three weight matrices once per block, coalesced (they are re-used by 16 rows)
+    for (int i = tid; i < C * C; i += 256) w_in[i] = a.win_t[i];
+    for (int i = tid; i < C * Hid; i += 256) w1[i] = a.w1_t[i];
+    for (int i = tid; i < Hid * Out; i += 256) w2[i] = a.w2_t[i];
+    const long row0 = (long)blockIdx.x * FAR_ROWS;
+    for (int i = tid; i < FAR_ROWS * C; i += 256) {
         const long row = row0 + i / C;
         vin[i] = row < a.rows ? a.m[row * C + (i % C)] : 0.0f;
     }
     __syncthreads();
-    for (int o = tid; o < C; o += 128) {
-        float acc[FAR_ROWS];
-#pragma unroll
-        for (int r = 0; r < FAR_ROWS; ++r) acc[r] = 0.0f;
-        for (int i = 0; i < C; ++i) {
-            const float w = a.win_t[i * C + o];
-#pragma unroll
-            for (int r = 0; r < FAR_ROWS; ++r) acc[r] += w * vin[r * C + i];
-        }
-#pragma unroll
-        for (int r = 0; r < FAR_ROWS; ++r) t[r * C + o] = acc[r];
+    for (int idx = tid; idx < FAR_ROWS * C; idx += 256) {       // to_in
+        const int r = idx / C, o = idx - r * C;
+        float acc = 0.0f;
+        for (int i = 0; i < C; ++i) acc += w_in[i * C + o] * vin[r * C + i];
+        t[idx] = acc;
     }
     __syncthreads();
-    if (tid < FAR_ROWS) {
+    if (tid < FAR_ROWS) {                                        // LayerNorm(C), eps 1e-5
         float s = 0.0f;
         for (int i = 0; i < C; ++i) s += t[tid * C + i];
         const float mean = s / (float)C;
         float q = 0.0f;
-        for (int i = 0; i < C; ++i) {
-            const float d = t[tid * C + i] - mean;
-            q += d * d;
-        }
-        stat[tid * 2] = mean;
-        stat[tid * 2 + 1] = 1.0f / sqrtf(q / (float)C + 1e-5f);
+        for (int i = 0; i < C; ++i) { const float d = t[tid * C + i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+        for (int i = 0; i < C; ++i) t[tid * C + i] = (t[tid * C + i] - mean) * rstd * a.ln_g[i] + a.ln_b[i];
     }
     __syncthreads();
-    for (int i = tid; i < FAR_ROWS * C; i += 128) {
-        const int r = i / C, c = i % C;
-        t[i] = (t[i] - stat[r * 2]) * stat[r * 2 + 1] * a.ln_g[c] + a.ln_b[c];
+    for (int idx = tid; idx < FAR_ROWS * Hid; idx += 256) {     // Linear(C, 2C) + GELU
+        const int r = idx / Hid, j = idx - r * Hid;
+        float acc = 0.0f;
+        for (int i = 0; i < C; ++i) acc += w1[i * Hid + j] * t[r * C + i];
+        hb[idx] = act_apply(acc, ACT_GELU);
     }
     __syncthreads();
-    for (int j = tid; j < Hid; j += 128) {
-        float acc[FAR_ROWS];
-#pragma unroll
-        for (int r = 0; r < FAR_ROWS; ++r) acc[r] = 0.0f;
-        for (int i = 0; i < C; ++i) {
-            const float w = a.w1_t[i * Hid + j];
-#pragma unroll
-            for (int r = 0; r < FAR_ROWS; ++r) acc[r] += w * t[r * C + i];
-        }
-#pragma unroll
-        for (int r = 0; r < FAR_ROWS; ++r) hb[r * Hid + j] = act_apply(acc[r], ACT_GELU);
-    }
-    __syncthreads();
-    for (int o = tid; o < Out; o += 128) {
-        float acc[FAR_ROWS];
-#pragma unroll
-        for (int r = 0; r < FAR_ROWS; ++r) acc[r] = 0.0f;
-        for (int j = 0; j < Hid; ++j) {
-            const float w = a.w2_t[j * Out + o];
-#pragma unroll
-            for (int r = 0; r < FAR_ROWS; ++r) acc[r] += w * hb[r * Hid + j];
-        }
-        const float bo = a.b2[o];
-#pragma unroll
-        for (int r = 0; r < FAR_ROWS; ++r) {
-            const long row = row0 + r;
-            if (row < a.rows) {
-                const long bi = row / a.n, i = row - bi * a.n;
-                a.u[(bi * Out + o) * a.n + i] = acc[r] + bo;
-            }
+    for (int idx = tid; idx < FAR_ROWS * Out; idx += 256) {     // Linear(2C, out) + bias
+        const int r = idx / Out, o = idx - r * Out;
+        float acc = a.b2[o];
+        for (int j = 0; j < Hid; ++j) acc += w2[j * Out + o] * hb[r * Hid + j];
+        const long row = row0 + r;
+        if (row < a.rows) {
+            const long bi = row / a.n, i = row - bi * a.n;
+            a.u[(bi * Out + o) * a.n + i] = acc;
         }
     }
 }
 
 hipError_t launch_fa_reducer(const FaReducerArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)FAR_ROWS * (2 * a.C + a.Hid + 2) * 4;
+    const size_t lds = ((size_t)a.C * a.C + (size_t)a.C * a.Hid + (size_t)a.Hid * a.Out +
+                        (size_t)FAR_ROWS * (2 * a.C + a.Hid)) * 4;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned nb = (unsigned)((a.rows + FAR_ROWS - 1) / FAR_ROWS);
-    hipLaunchKernelGGL(fa_reducer_kernel, dim3(nb), dim3(128), lds, s, a);
+    hipLaunchKernelGGL(fa_reducer_kernel, dim3(nb), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -908,15 +908,15 @@ hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s) {
 // accumulator registers (two-pass, exact) and applied before the store.
 // ===========================================================================
 template <int HT, int WT, bool VEC>
-__global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int planes_per_block) {
+__global__ __launch_bounds__(256, (HT * WT >= 6 ? 1 : 2)) void fa_sandwich_kernel(FaSandwichArgs a, int planes_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HP = HT * 32 + 1, WP = WT * 32 + 1;
-    // plane prefetch registers: one 64-lane wave moves a whole (padded) plane
-    constexpr int NPF = (HT * 32) * (WT * 32) / 64;        // floats per lane
-    constexpr int NQ = VEC ? NPF / 4 : NPF;                // load instructions per lane
+    // plane prefetch registers: one 64-lane wave moves a whole (padded) plane, 32 rows at a time
+    constexpr int NPH = 32 * (WT * 32) / 64;               // floats per lane per 32-row band
+    constexpr int NQH = VEC ? NPH / 4 : NPH;               // load instructions per lane per band
     float* Kxs = reinterpret_cast<float*>(smem);          // [HT*32][HP]
     float* Kys = Kxs + HT * 32 * HP;                      // [WT*32][WP]
-    float* Pall = Kys + WT * 32 * WP;                     // 4 x [HT*32][WP]
+    float* Pall = Kys + WT * 32 * WP;                     // 4 x [32][WP]  (one 32-row band per wave)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int H = a.H, W = a.W, C = a.C;
@@ -931,28 +931,30 @@ __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int 
         const int r = i / (WT * 32), c = i - r * (WT * 32);
         Kys[r * WP + c] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
     }
-    float* Ps = Pall + wave * (HT * 32 * WP);
-    for (int i = lane; i < HT * 32 * WP; i += 64) Ps[i] = 0.0f;   // padding stays zero for every plane
+    float* Ps = Pall + wave * (32 * WP);
+    for (int i = lane; i < 32 * WP; i += 64) Ps[i] = 0.0f;   // column padding stays zero for every band
     __syncthreads();
 
-    // per-lane source / LDS offsets of the plane elements this lane moves (same for every plane)
-    int soff[NQ], doff[NQ];
+    // per-lane offsets inside a 32-row band (the same for every band / plane)
+    int soff[NQH], doff[NQH];
     {
         const int per_row = VEC ? W / 4 : W;
-        const int nvalid = H * per_row;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+        for (int q = 0; q < NQH; ++q) {
             const int f = lane + 64 * q;
             const int r = f / per_row, c = (f - r * per_row) * (VEC ? 4 : 1);
-            soff[q] = f < nvalid ? r * W + c : -1;
+            soff[q] = r < 32 ? r * W + c : -1;
             doff[q] = r * WP + c;
         }
     }
-    float pf[NPF];
-    auto prefetch = [&](const float* pg) __attribute__((always_inline)) {
+    // band-level pipeline: while the MFMAs of band jt run, the loads of the next band (same plane
+    // or band 0 of this wave's next plane) are in flight in registers
+    float pf[NPH];
+    auto prefetch = [&](const float* pg, int jt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int so = soff[q] < 0 ? 0 : soff[q];      // unconditional, clamped
+        for (int q = 0; q < NQH; ++q) {
+            const bool ok = soff[q] >= 0 && (jt * 32 + soff[q] / W) < H;
+            const int so = ok ? jt * 32 * W + soff[q] : 0;   // clamped: loads are unconditional
             if (VEC) {
                 const float4 t = *reinterpret_cast<const float4*>(pg + so);
                 pf[4 * q] = t.x; pf[4 * q + 1] = t.y; pf[4 * q + 2] = t.z; pf[4 * q + 3] = t.w;
@@ -967,25 +969,9 @@ __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int 
     const long plane0 = ((long)b * a.heads + h) * C;
     int c = c_begin + wave;
     const int c_end = min(c_begin + planes_per_block, C);
-    if (c < c_end) prefetch(a.u + (plane0 + c) * H * W);
+    if (c < c_end) prefetch(a.u + (plane0 + c) * H * W, 0);
+    const int kpairs = (W + 1) >> 1;
     for (; c < c_end; c += 4) {
-        // registers -> this wave's private LDS plane (row-major, odd row stride: the column
-        // reads of the first product are bank-conflict free).  No block barrier: LDS
-        // operations of one wave execute in order.
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (soff[q] >= 0) {
-                if (VEC) {
-                    Ps[doff[q]] = pf[4 * q]; Ps[doff[q] + 1] = pf[4 * q + 1];
-                    Ps[doff[q] + 2] = pf[4 * q + 2]; Ps[doff[q] + 3] = pf[4 * q + 3];
-                } else {
-                    Ps[doff[q]] = pf[q];
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (c + 4 < c_end) prefetch(a.u + (plane0 + c + 4) * H * W);   // in flight during the MFMAs
-
         f32x16 Y[HT][WT];
 #pragma unroll
         for (int i = 0; i < HT; ++i)
@@ -993,31 +979,48 @@ __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int 
             for (int j = 0; j < WT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Y[i][j][r] = 0.0f;
-        const int kpairs = (W + 1) >> 1;
 #pragma unroll
-        for (int lt = 0; lt < WT; ++lt) {
-            f32x16 U[HT];
+        for (int jt = 0; jt < HT; ++jt) {
+            // band jt of the plane: registers -> this wave's private LDS band (row-major, odd row
+            // stride: the column reads below are bank-conflict free).  No block barrier: LDS
+            // operations of one wave execute in order.
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) U[jt][r] = 0.0f;
-            const float* kyp = Kys + (lt * 32 + l31) * WP + kh;
-            const float* pp = Ps + l31 * WP + kh;
-#pragma unroll 4
-            for (int kk = 0; kk < kpairs; ++kk) {
-                const float bv = kyp[2 * kk];
-#pragma unroll
-                for (int jt = 0; jt < HT; ++jt)
-                    U[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pp[jt * 32 * WP + 2 * kk], bv, U[jt], 0, 0, 0);
+            for (int q = 0; q < NQH; ++q) {
+                const bool ok = soff[q] >= 0 && (jt * 32 + soff[q] / W) < H;
+                if (soff[q] >= 0) {          // slots past the 32-row band do not exist
+                    if (VEC) {
+                        Ps[doff[q]] = ok ? pf[4 * q] : 0.0f; Ps[doff[q] + 1] = ok ? pf[4 * q + 1] : 0.0f;
+                        Ps[doff[q] + 2] = ok ? pf[4 * q + 2] : 0.0f; Ps[doff[q] + 3] = ok ? pf[4 * q + 3] : 0.0f;
+                    } else {
+                        Ps[doff[q]] = ok ? pf[q] : 0.0f;
+                    }
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            if (jt + 1 < HT) prefetch(a.u + (plane0 + c) * H * W, jt + 1);
+            else if (c + 4 < c_end) prefetch(a.u + (plane0 + c + 4) * H * W, 0);
 #pragma unroll
-            for (int it = 0; it < HT; ++it)
+            for (int lt = 0; lt < WT; ++lt) {
+                f32x16 U;                                  // U[j][l] = sum_m P[j][m] Ky[l][m]
 #pragma unroll
-                for (int jt = 0; jt < HT; ++jt)
+                for (int r = 0; r < 16; ++r) U[r] = 0.0f;
+                const float* kyp = Kys + (lt * 32 + l31) * WP + kh;
+                const float* pp = Ps + l31 * WP + kh;
+#pragma unroll 8
+                for (int kk = 0; kk < kpairs; ++kk)
+                    U = __builtin_amdgcn_mfma_f32_32x32x2f32(pp[2 * kk], kyp[2 * kk], U, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's LDS-read hoisting (registers)
+                // Y[i][l] += sum_{j in band} Kx[i][j] U[j][l]: U's accumulator registers are the B operand
+#pragma unroll
+                for (int it = 0; it < HT; ++it) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         Y[it][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            Kxs[(it * 32 + l31) * HP + jt * 32 + drow(r, kh)], U[jt][r], Y[it][lt], 0, 0, 0);
+                            Kxs[(it * 32 + l31) * HP + jt * 32 + drow(r, kh)], U[r], Y[it][lt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         float mean = 0.0f, rstd = 1.0f;
         if (a.instnorm) {
@@ -1055,14 +1058,13 @@ __global__ __launch_bounds__(256) void fa_sandwich_kernel(FaSandwichArgs a, int 
                     const int i = it * 32 + drow(r, kh), l = lt * 32 + l31;
                     if (i < H && l < W) og[i * W + l] = (Y[it][lt][r] - mean) * rstd;
                 }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
 size_t fa_sandwich_lds_bytes(int H, int W) {
     const int HT = (H + 31) / 32, WT = (W + 31) / 32;
     const size_t HP = HT * 32 + 1, WP = WT * 32 + 1;
-    return (HT * 32 * HP + WT * 32 * WP + 4 * HT * 32 * WP) * 4;
+    return (HT * 32 * HP + WT * 32 * WP + 4 * 32 * WP) * 4;
 }
 
 template <int HT, int WT>

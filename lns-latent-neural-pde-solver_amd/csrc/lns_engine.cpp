@@ -954,10 +954,13 @@ struct Runner {
 };
 
 // workspace layout: [ z ping | z pong | arena ]
-struct WsLayout { size_t z_bytes, arena_off, total; };
+// workspace layout: [ z ring (ZRING latents) | arena A (encode / decode plans) | arena B (propagator plan) ]
+// The propagator gets its own arena because it runs on a second stream, concurrently with decode.
+enum { ZRING = 4 };
+struct WsLayout { size_t z_bytes, arena_off, prop_off, total; };
 
 static int ws_layout(lns_engine* e, int B, WsLayout* L) {
-    size_t arena = 0;
+    size_t arena = 0, parena = 0;
     Plan* p;
     int rc;
     if (!e->enc.empty()) {
@@ -968,11 +971,24 @@ static int ws_layout(lns_engine* e, int B, WsLayout* L) {
     }
     if (!e->prop.empty() && e->lat_H > 0) {
         if ((rc = get_plan(e, PK_PROP, B, e->lat_H, e->lat_W, &p))) return rc;
-        arena = std::max(arena, p->arena_bytes);
+        parena = p->arena_bytes;
     }
     L->z_bytes = round_up_sz((size_t)B * std::max(1, e->lat_C) * std::max(1, e->lat_H) * std::max(1, e->lat_W) * 4, 256);
-    L->arena_off = 2 * L->z_bytes;
-    L->total = L->arena_off + arena + 256;
+    L->arena_off = ZRING * L->z_bytes;
+    L->prop_off = L->arena_off + round_up_sz(arena, 256);
+    L->total = L->prop_off + round_up_sz(parena, 256) + 256;
+    return LNS_OK;
+}
+
+// second stream + events for the propagate / decode overlap (created once, owned by the engine)
+static int ensure_overlap_objects(lns_engine* e) {
+    if (e->side_stream) return LNS_OK;
+    HIPCHK(e, hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&e->side_stream), hipStreamNonBlocking));
+    for (int i = 0; i < 2 * ZRING + 2; ++i) {
+        hipEvent_t ev;
+        HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->events.push_back(ev);
+    }
     return LNS_OK;
 }
 
@@ -1010,6 +1026,8 @@ void lns_destroy(lns_engine* e) {
     for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans})
         for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
     if (e->d_weights) (void)hipFree(e->d_weights);
+    for (void* ev : e->events) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
+    if (e->side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(e->side_stream));
     delete e;
 }
 
@@ -1119,6 +1137,10 @@ int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, i
 }
 
 // shared autoregressive loop: zcur -> T x (propagate ; decode)   (train_stage2_ns2d.py:147-156)
+// The latent chain z_t -> z_{t+1} is strictly sequential, but decode(z_t) depends on z_t only:
+// with to_x the propagator chain runs on the engine's side stream (own arena, ring of ZRING
+// latents) and the decodes on the caller's stream, ordered by events, so the small latent-resolution
+// kernels of step t+1 overlap the large decode kernels of step t.
 static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param, int B, int T, int to_x, float* out,
                         float* latents_out, float* z_last, const WsLayout& L, char* base) {
     Plan *pp, *pd;
@@ -1128,33 +1150,73 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
     const lns_config& c = e->cfg;
     const long zper = (long)e->lat_C * e->lat_H * e->lat_W;
     const long xper = (long)c.in_channels * c.Ly * c.Lx;
-    float* zbuf[2] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + L.z_bytes)};
     char* arena = base + L.arena_off;
+    char* parena = base + L.prop_off;
     hipStream_t stream = r.stream;
     ExtT ext[EX_COUNT];
     ext[EX_PARAM] = {param, 1};
-    int pong = (zcur.ptr == zbuf[0]) ? 1 : 0;
-    for (int t = 0; t < T; ++t) {   // strictly sequential in t, independent in b
-        ExtT znext;
-        if (latents_out) znext = {latents_out + (long)t * zper, (long)T * zper};
-        else if (!to_x) znext = {out + (long)t * zper, (long)T * zper};
-        else { znext = {zbuf[pong], zper}; pong ^= 1; }
+    static const bool no_overlap = getenv("LNS_NO_OVERLAP") != nullptr;
+    const bool overlap = to_x && !latents_out && !e->trace_on && !e->timing_on && !no_overlap;
+    if (!overlap) {
+        // single-stream path (latent-only rollouts, diagnostics)
+        int slot = 1;
+        for (int t = 0; t < T; ++t) {   // strictly sequential in t, independent in b
+            ExtT znext;
+            if (latents_out) znext = {latents_out + (long)t * zper, (long)T * zper};
+            else if (!to_x) znext = {out + (long)t * zper, (long)T * zper};
+            else { znext = {base + (size_t)slot * L.z_bytes, zper}; slot = slot % (ZRING - 1) + 1; }
+            ext[EX_IN] = zcur;
+            ext[EX_OUT] = znext;
+            if ((rc = r.run(*pp, ext, parena))) return rc;
+            if (to_x) {
+                ext[EX_IN] = znext;
+                ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
+                if ((rc = r.run(*pd, ext, arena))) return rc;
+            } else if (latents_out) {
+                HIPCHK(e, hipMemcpy2DAsync(out + (long)t * zper, (size_t)T * zper * 4, znext.ptr, (size_t)T * zper * 4,
+                                           (size_t)zper * 4, B, hipMemcpyDeviceToDevice, stream));
+            }
+            zcur = znext;
+        }
+        if (z_last)
+            HIPCHK(e, hipMemcpy2DAsync(z_last, (size_t)zper * 4, zcur.ptr, (size_t)zcur.bs * 4, (size_t)zper * 4, B,
+                                       hipMemcpyDeviceToDevice, stream));
+        return LNS_OK;
+    }
+    if ((rc = ensure_overlap_objects(e))) return rc;
+    hipStream_t pstream = static_cast<hipStream_t>(e->side_stream);
+    Runner rp(e, pstream);
+    hipEvent_t* ev_z = e->events.data();             // ev_z[s]: latent in ring slot s is complete
+    hipEvent_t* ev_free = e->events.data() + ZRING;  // ev_free[s]: decode has finished reading ring slot s
+    hipEvent_t ev_start = e->events[2 * ZRING], ev_end = e->events[2 * ZRING + 1];
+    // ring slot 0 is never written by the loop (it may hold the caller's / encoder's z0)
+    HIPCHK(e, hipEventRecord(ev_start, stream));
+    HIPCHK(e, hipStreamWaitEvent(pstream, ev_start, 0));
+    int slot = 1;
+    std::vector<char> used(ZRING, 0);
+    for (int t = 0; t < T; ++t) {
+        const int s = slot;
+        slot = slot % (ZRING - 1) + 1;              // 1, 2, 3, 1, ...
+        ExtT znext = {base + (size_t)s * L.z_bytes, zper};
+        if (used[s]) HIPCHK(e, hipStreamWaitEvent(pstream, ev_free[s], 0));   // WAR: decode(t - (ZRING-1)) done
         ext[EX_IN] = zcur;
         ext[EX_OUT] = znext;
-        if ((rc = r.run(*pp, ext, arena))) return rc;
-        if (to_x) {
-            ext[EX_IN] = znext;
-            ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
-            if ((rc = r.run(*pd, ext, arena))) return rc;
-        } else if (latents_out) {
-            HIPCHK(e, hipMemcpy2DAsync(out + (long)t * zper, (size_t)T * zper * 4, znext.ptr, (size_t)T * zper * 4,
-                                       (size_t)zper * 4, B, hipMemcpyDeviceToDevice, stream));
-        }
+        if ((rc = rp.run(*pp, ext, parena))) return rc;
+        HIPCHK(e, hipEventRecord(ev_z[s], pstream));
+        HIPCHK(e, hipStreamWaitEvent(stream, ev_z[s], 0));
+        ext[EX_IN] = znext;
+        ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
+        if ((rc = r.run(*pd, ext, arena))) return rc;
+        HIPCHK(e, hipEventRecord(ev_free[s], stream));
+        used[s] = 1;
         zcur = znext;
     }
     if (z_last)
         HIPCHK(e, hipMemcpy2DAsync(z_last, (size_t)zper * 4, zcur.ptr, (size_t)zcur.bs * 4, (size_t)zper * 4, B,
                                    hipMemcpyDeviceToDevice, stream));
+    // join: everything the side stream did is ordered before whatever the caller enqueues next
+    HIPCHK(e, hipEventRecord(ev_end, pstream));
+    HIPCHK(e, hipStreamWaitEvent(stream, ev_end, 0));
     return LNS_OK;
 }
 

@@ -126,6 +126,9 @@ struct lns_engine {
     int device = -1;
     // plans keyed by batch (encode/decode) or (B,H,W) for the propagator
     std::map<long, lns::Plan> enc_plans, dec_plans, prop_plans;
+    // propagate / decode overlap
+    void* side_stream = nullptr;
+    std::vector<hipEvent_t> events;
     // diagnostics
     bool trace_on = false;
     std::vector<lns::TraceRec> trace;

@@ -288,16 +288,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
             const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
             const float* wbase = Ws + wm * (MT * 32) + l31 + kh * TM;
             const float* xbase = Xs + kh * PLANE;
-            float av[2][MT], bv[2][NT];
-            load_ops(0, wbase, xbase, av[0], bv[0]);
+            // operand look-ahead: LA steps of LDS reads are in flight while a step's MFMAs execute
+            // (small per-wave tiles have short steps, so they look further ahead)
+            constexpr int LA = (MT * NT <= 2) ? 2 : 1;
+            float av[LA + 1][MT], bv[LA + 1][NT];
+#pragma unroll
+            for (int p = 0; p < LA; ++p)
+                if (p < NSTEP) load_ops(p, wbase, xbase, av[p], bv[p]);
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
-                if (s + 1 < NSTEP) load_ops(s + 1, wbase, xbase, av[(s + 1) & 1], bv[(s + 1) & 1]);
+                if (s + LA < NSTEP) load_ops(s + LA, wbase, xbase, av[(s + LA) % (LA + 1)], bv[(s + LA) % (LA + 1)]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt], bv[s & 1][nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % (LA + 1)][mt], bv[s % (LA + 1)][nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < SPS; ++u) {
                     const int q = s * SPS + u;

@@ -956,8 +956,8 @@ struct Runner {
 // workspace layout: [ z ping | z pong | arena ]
 // workspace layout: [ z ring (ZRING latents) | arena A (encode / decode plans) | arena B (propagator plan) ]
 // The propagator gets its own arena because it runs on a second stream, concurrently with decode.
-enum { ZRING = 4, NDEC = 2 };   // latents in flight; decode streams (alternating steps)
-struct WsLayout { size_t z_bytes, arena_off, arena2_off, prop_off, total; };
+enum { ZRING = 6, NDEC = 4 };   // latents in flight; max decode streams (steps round-robin)
+struct WsLayout { size_t z_bytes, arena_off, arena_stride, prop_off, total; int ndec; };
 
 static int ws_layout(lns_engine* e, int B, WsLayout* L) {
     size_t arena = 0, parena = 0;
@@ -974,9 +974,11 @@ static int ws_layout(lns_engine* e, int B, WsLayout* L) {
         parena = p->arena_bytes;
     }
     L->z_bytes = round_up_sz((size_t)B * std::max(1, e->lat_C) * std::max(1, e->lat_H) * std::max(1, e->lat_W) * 4, 256);
+    static const int ndec_env = getenv("LNS_DECODE_STREAMS") ? atoi(getenv("LNS_DECODE_STREAMS")) : 3;
+    L->ndec = std::min((int)NDEC, std::max(1, ndec_env));
     L->arena_off = ZRING * L->z_bytes;
-    L->arena2_off = L->arena_off + round_up_sz(arena, 256);          // second decode arena (odd steps)
-    L->prop_off = L->arena2_off + round_up_sz(arena, 256);
+    L->arena_stride = round_up_sz(arena, 256);                        // one decode arena per decode stream
+    L->prop_off = L->arena_off + (size_t)L->ndec * L->arena_stride;
     L->total = L->prop_off + round_up_sz(parena, 256) + 256;
     return LNS_OK;
 }
@@ -985,8 +987,12 @@ static int ws_layout(lns_engine* e, int B, WsLayout* L) {
 static int ensure_overlap_objects(lns_engine* e) {
     if (e->side_stream) return LNS_OK;
     HIPCHK(e, hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&e->side_stream), hipStreamNonBlocking));
-    HIPCHK(e, hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&e->side_stream2), hipStreamNonBlocking));
-    for (int i = 0; i < 2 * ZRING + 3; ++i) {
+    for (int i = 0; i < NDEC - 1; ++i) {
+        hipStream_t st;
+        HIPCHK(e, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        e->dec_streams.push_back(st);
+    }
+    for (int i = 0; i < 2 * ZRING + 1 + NDEC; ++i) {
         hipEvent_t ev;
         HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         e->events.push_back(ev);
@@ -1030,7 +1036,7 @@ void lns_destroy(lns_engine* e) {
     if (e->d_weights) (void)hipFree(e->d_weights);
     for (void* ev : e->events) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
     if (e->side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(e->side_stream));
-    if (e->side_stream2) (void)hipStreamDestroy(static_cast<hipStream_t>(e->side_stream2));
+    for (hipStream_t st : e->dec_streams) (void)hipStreamDestroy(st);
     delete e;
 }
 
@@ -1188,36 +1194,42 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
     }
     if ((rc = ensure_overlap_objects(e))) return rc;
     hipStream_t pstream = static_cast<hipStream_t>(e->side_stream);
-    static const bool one_dec = getenv("LNS_ONE_DECODE_STREAM") != nullptr;
-    // decodes of consecutive steps are independent too: even steps on the caller's stream, odd
-    // steps on a second side stream with its own arena
-    hipStream_t dstream[NDEC] = {stream, one_dec ? stream : static_cast<hipStream_t>(e->side_stream2)};
-    char* darena[NDEC] = {arena, one_dec ? arena : base + L.arena2_off};
+    // decodes of different steps are independent too: step t runs on decode stream t % ndec
+    // (stream 0 = the caller's), each with its own arena
+    const int ndec = L.ndec;
+    hipStream_t dstream[NDEC];
+    char* darena[NDEC];
+    std::vector<Runner> rd;
+    for (int d = 0; d < ndec; ++d) {
+        dstream[d] = d == 0 ? stream : e->dec_streams[d - 1];
+        darena[d] = arena + (size_t)d * L.arena_stride;
+        rd.emplace_back(e, dstream[d]);
+    }
     Runner rp(e, pstream);
-    Runner rd1(e, dstream[1]);
     hipEvent_t* ev_z = e->events.data();             // ev_z[s]: latent in ring slot s is complete
     hipEvent_t* ev_free = e->events.data() + ZRING;  // ev_free[s]: decode has finished reading ring slot s
-    hipEvent_t ev_start = e->events[2 * ZRING], ev_end = e->events[2 * ZRING + 1], ev_end2 = e->events[2 * ZRING + 2];
+    hipEvent_t ev_start = e->events[2 * ZRING];
+    hipEvent_t* ev_end = e->events.data() + 2 * ZRING + 1;   // [0]: propagator stream, [d]: decode stream d
     // ring slot 0 is never written by the loop (it may hold the caller's / encoder's z0)
     HIPCHK(e, hipEventRecord(ev_start, stream));
     HIPCHK(e, hipStreamWaitEvent(pstream, ev_start, 0));
-    if (dstream[1] != stream) HIPCHK(e, hipStreamWaitEvent(dstream[1], ev_start, 0));
+    for (int d = 1; d < ndec; ++d) HIPCHK(e, hipStreamWaitEvent(dstream[d], ev_start, 0));
     int slot = 1;
     std::vector<char> used(ZRING, 0);
     for (int t = 0; t < T; ++t) {
         const int s = slot;
-        slot = slot % (ZRING - 1) + 1;              // 1, 2, 3, 1, ...
+        slot = slot % (ZRING - 1) + 1;              // 1, 2, ..., ZRING-1, 1, ...
         ExtT znext = {base + (size_t)s * L.z_bytes, zper};
         if (used[s]) HIPCHK(e, hipStreamWaitEvent(pstream, ev_free[s], 0));   // WAR: decode(t - (ZRING-1)) done
         ext[EX_IN] = zcur;
         ext[EX_OUT] = znext;
         if ((rc = rp.run(*pp, ext, parena))) return rc;
         HIPCHK(e, hipEventRecord(ev_z[s], pstream));
-        const int d = t % NDEC;
+        const int d = t % ndec;
         HIPCHK(e, hipStreamWaitEvent(dstream[d], ev_z[s], 0));
         ext[EX_IN] = znext;
         ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
-        if ((rc = (d == 0 ? r : rd1).run(*pd, ext, darena[d]))) return rc;
+        if ((rc = rd[d].run(*pd, ext, darena[d]))) return rc;
         HIPCHK(e, hipEventRecord(ev_free[s], dstream[d]));
         used[s] = 1;
         zcur = znext;
@@ -1228,11 +1240,11 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
                                    hipMemcpyDeviceToDevice, pstream));
     }
     // join: everything the side streams did is ordered before whatever the caller enqueues next
-    HIPCHK(e, hipEventRecord(ev_end, pstream));
-    HIPCHK(e, hipStreamWaitEvent(stream, ev_end, 0));
-    if (dstream[1] != stream) {
-        HIPCHK(e, hipEventRecord(ev_end2, dstream[1]));
-        HIPCHK(e, hipStreamWaitEvent(stream, ev_end2, 0));
+    HIPCHK(e, hipEventRecord(ev_end[0], pstream));
+    HIPCHK(e, hipStreamWaitEvent(stream, ev_end[0], 0));
+    for (int d = 1; d < ndec; ++d) {
+        HIPCHK(e, hipEventRecord(ev_end[d], dstream[d]));
+        HIPCHK(e, hipStreamWaitEvent(stream, ev_end[d], 0));
     }
     return LNS_OK;
 }

@@ -128,7 +128,7 @@ struct lns_engine {
     std::map<long, lns::Plan> enc_plans, dec_plans, prop_plans;
     // propagate / decode overlap
     void* side_stream = nullptr;
-    void* side_stream2 = nullptr;
+    std::vector<hipStream_t> dec_streams;
     std::vector<hipEvent_t> events;
     // diagnostics
     bool trace_on = false;

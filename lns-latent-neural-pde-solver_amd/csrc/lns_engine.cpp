@@ -152,7 +152,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         g.cout_tiles = (Cout + vi.TM - 1) / vi.TM;
         g.PH = tmp.PH; g.PW = tmp.PW; g.sel_kc_log2 = best_kc;
         found = true;
-        static const long min_blocks = getenv("LNS_CONV_MIN_BLOCKS") ? atol(getenv("LNS_CONV_MIN_BLOCKS")) : 256;
+        static const long min_blocks = getenv("LNS_CONV_MIN_BLOCKS") ? atol(getenv("LNS_CONV_MIN_BLOCKS")) : 128;
         if (blocks >= min_blocks) break;
     }
     return found;

@@ -80,8 +80,13 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="single-stream execution (no propagate/decode overlap): the mode the per-kernel roofline "
+                         "pass uses; profile THIS mode to compare rocprofv3 averages with the roofline block")
     a = ap.parse_args()
 
+    if a.serial:
+        os.environ["LNS_NO_OVERLAP"] = "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,14 +157,17 @@ def main():
         "config": {"workload": "NS2d 128x128 3-channel, %d-step latent rollout, batch=%d per GPU "
                                "(BASELINE.json configs[1])" % (T, B),
                    "preset": a.preset, "batch_per_gpu": B, "rollout_steps": T, "global_batch": B * n_gpus,
-                   "parallelism": "trajectory-sharded x%d%s" % (n_gpus, ", overlapped all-gather" if gather else "")},
+                   "parallelism": "trajectory-sharded x%d%s" % (n_gpus, ", overlapped all-gather" if gather else ""),
+                   "streams": "single stream" if a.serial else "propagator + 3 decode streams per GPU"},
         "batch_steps_per_s": value / B,
         "path_tflops_per_gpu": (FLOP_PER_TRAJ_STEP * B * T + FLOP_ENCODE * B) * a.steps / dt / 1e12,
     }
 
     if rank == 0 and not a.no_roofline:
-        # per-kernel-class HIP-event timing of one more pass on the same stream (events are
-        # recorded around every launch inside the engine; kept out of `value`'s timed region)
+        # per-kernel-class HIP-event timing of one more pass (events recorded around every launch
+        # inside the engine, on the stream the kernel is launched on).  The engine runs this
+        # diagnostic pass single-stream, so kernel durations are not inflated by co-running
+        # kernels; it is kept out of `value`'s timed region.
         eng.timing_enable(True)
         eng.rollout(x, T, to_x=True, out=out)
         torch.cuda.synchronize()
@@ -173,6 +181,8 @@ def main():
                 "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
                 "traffic": None, "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
                 "algorithmic_flop_per_launch": k["flops"] / k["launches"],
+                "mode": "single-stream diagnostic pass (python bench.py --serial reproduces it under rocprofv3)",
+                "whole_path_frac_of_mfma_peak": result["path_tflops_per_gpu"] / FP32_MFMA_PEAK_TFLOPS,
             }
         tot = sum(v["ms"] for v in tm.values())
         result["kernel_classes"] = {n: {"ms": round(v["ms"], 3), "share": round(v["ms"] / tot, 4),

@@ -78,6 +78,27 @@ def run_trace(preset):
         say("FAIL trace", preset, traceback.format_exc()[-1500:])
 
 
+
+
+def run_golden(case):
+    """rollout error vs the REAL reference's golden fixture (and vs its fp64 run) per stored step"""
+    from helpers import load_golden, case_args, case_inputs, rel_l2
+    meta, g = load_golden(case)
+    args = case_args(meta)
+    model, _ = gc.build_models(args, meta["weight_seed"])
+    x, param = case_inputs(meta, args)
+    xd = torch.from_numpy(x).cuda()
+    extra = (torch.from_numpy(param).cuda(),) if param is not None else ()
+    dec, lat = model.predict(xd, meta["T"], *extra, to_x=True, return_latents=True)
+    dec, lat = dec.cpu().numpy(), lat.cpu().numpy()
+    sub = meta["sub"]
+    say("== golden", case, "(step: hip-vs-ref32 latent, decoded | hip-vs-ref64 decoded | ref32-vs-ref64 decoded)")
+    for i, s in enumerate(meta["steps"]):
+        say("   t=%3d  %.2e %.2e | %.2e | %.2e" % (
+            s, rel_l2(lat[:, s - 1], g["lat"][:, i]), rel_l2(dec[:, s - 1][..., ::sub, ::sub], g["dec"][:, i]),
+            rel_l2(dec[:, s - 1][..., ::sub, ::sub], g["dec_f64"][:, i]), float(g["ref_self_err"][s - 1])))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "trace:ns2d_mini", "trace:ns2d_128"]
     say("# gpu_diag", time.ctime(), torch.cuda.get_device_name(0))
@@ -86,4 +107,6 @@ if __name__ == "__main__":
             run_ops()
         elif w.startswith("trace:"):
             run_trace(w.split(":", 1)[1])
+        elif w.startswith("golden:"):
+            run_golden(w.split(":", 1)[1])
     say("# done")

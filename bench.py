@@ -68,6 +68,24 @@ def cpu_baseline(args, sd, B, T):
                 sample="NS2d 128x128x3, B=%d, T=%d, predict(to_x=True), %.1f s" % (B, T, dt))
 
 
+def traffic_from_profiles(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs; see profiles/*_traffic.json for the corrections).
+    bench.py cannot run the profiler itself; null when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        k = d["kernels"][kernel]
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "unit": "B", "source": os.path.basename(files[-1]),
+                "profiled_kernel": k["kernel"]}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,8 +197,9 @@ def main():
             result["roofline"] = {
                 "kernel": "conv_mfma_kernel (3x3 implicit GEMM, fp32 MFMA)", "bound": "mfma",
                 "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None, "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
+                "traffic": traffic_from_profiles("conv3x3"), "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
                 "algorithmic_flop_per_launch": k["flops"] / k["launches"],
+                "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
                 "mode": "single-stream diagnostic pass (python bench.py --serial reproduces it under rocprofv3)",
                 "whole_path_frac_of_mfma_peak": result["path_tflops_per_gpu"] / FP32_MFMA_PEAK_TFLOPS,
             }

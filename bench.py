@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--preset", default="ns2d_128")
     ap.add_argument("--gather-chunk", type=int, default=16, help="step-block size of the overlapped all-gather")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (rehearsal on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true",
@@ -113,13 +115,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = a.device if a.device is not None else local_rank
+        torch.cuda.set_device(dev_index)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(a.dist_backend)
     elif a.gpus != 1:
         print("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE unset); running 1 GPU" % a.gpus,
               file=sys.stderr)
     n_gpus = world
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", a.device if a.device is not None else local_rank)
     torch.cuda.set_device(dev)
 
     from lns_amd import filler

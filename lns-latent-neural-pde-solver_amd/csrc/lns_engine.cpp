@@ -1004,6 +1004,18 @@ static int ensure_overlap_objects(lns_engine* e) {
 
 using namespace lns;
 
+// launches must target the device that holds the packed weights, whatever the caller's current device is
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(const lns_engine* e) {
+        if (e->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != e->device)
+            switched = hipSetDevice(e->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -1086,6 +1098,7 @@ int lns_latent_shape(const lns_engine* e, int* C, int* H, int* W) {
 
 int lns_prepare(lns_engine* e, int B, size_t* workspace_bytes) {
     if (!e || B <= 0) return LNS_EINVAL;
+    DeviceGuard dg(e);
     WsLayout L;
     int rc = ws_layout(e, B, &L);
     if (rc) return rc;
@@ -1100,6 +1113,7 @@ static int check_ws(lns_engine* e, const WsLayout& L, void* ws, size_t bytes) {
 
 int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
     if (!e || !x || !z || B <= 0) return LNS_EINVAL;
+    DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
     Plan* p;
@@ -1115,6 +1129,7 @@ int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t 
 
 int lns_decode(lns_engine* e, const float* z, int B, float* y, void* ws, size_t ws_bytes, void* stream) {
     if (!e || !z || !y || B <= 0) return LNS_EINVAL;
+    DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
     Plan* p;
@@ -1132,6 +1147,7 @@ int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, i
                   size_t ws_bytes, void* stream) {
     if (!e || !z_in || !z_out || B <= 0 || H <= 0 || W <= 0) return LNS_EINVAL;
     if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    DeviceGuard dg(e);
     Plan* p; int rc;
     if ((rc = get_plan(e, PK_PROP, B, H, W, &p))) return rc;
     if (!ws || ws_bytes < p->arena_bytes) { e->err = fmt("workspace too small: need %zu bytes", p->arena_bytes); return LNS_ENOMEM; }
@@ -1254,6 +1270,7 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
     if (!e || !x || !out || B <= 0 || T <= 0) return LNS_EINVAL;
     if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
     if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
     Plan* pe;
@@ -1278,6 +1295,7 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
     if (!e || !z_in || !out || B <= 0 || T <= 0) return LNS_EINVAL;
     if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
     if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
     Runner r(e, static_cast<hipStream_t>(stream));

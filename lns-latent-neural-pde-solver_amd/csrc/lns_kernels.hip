@@ -268,6 +268,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     // holding stage c+1 into the other buffer and (b) re-fills each register, as soon as it is
     // free, with stage c+2 from global memory.  Staging is spread over the MFMA steps, so the
     // matrix pipe is not idle while a wave stages; one barrier per stage.
+    // patch slots actually used by this launch (the compile-time bound covers the largest patch)
+    const int nused = KS == 3 ? (KC * PLANE + NTHR - 1) / NTHR
+                              : (VEC ? (KC * (TN / 4) + NTHR - 1) / NTHR : (KC * TN + NTHR - 1) / NTHR);
     auto k_loop = [&](auto mode_tag) __attribute__((always_inline)) {
         const int last = a.Cin_pad - KC;
 #pragma unroll
@@ -306,7 +309,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 #pragma unroll
                 for (int u = 0; u < SPS; ++u) {
                     const int q = s * SPS + u;
-                    if (q < NSLOT) {
+                    // patch slots beyond this launch's patch size do nothing (uniform skip)
+                    if (q < NSLOT && (q >= NDESC || q < nused)) {
                         write_slot(mode_tag, q, cw, Xn, Wn);
                         load_slot(q, cl2);
                     }

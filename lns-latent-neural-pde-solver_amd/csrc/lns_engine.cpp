@@ -99,14 +99,14 @@ static void pack_conv_weight(float* dst, const float* src, int cout_off, int cou
 struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Hout, Wout, kc_log2, sel_kc_log2; };
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
-                          int kc_log2_pack, int Cout_pad, int force_variant) {
+                          int kc_log2_pack, int Cout_pad, int force_variant, bool need_wgm1 = false) {
     g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
     g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
     if (g.Hout <= 0 || g.Wout <= 0) return false;
     std::vector<int> cands;
     if (force_variant >= 0) cands = {force_variant};
     else if (Cout <= 32) cands = {CV_S32};
-    else if (Cout <= 64) cands = {CV_L64, CV_M64, CV_S64};
+    else if (Cout <= 64) cands = need_wgm1 ? std::vector<int>{CV_L64, CV_M64} : std::vector<int>{CV_L64, CV_M64, CV_S64};
     else if (getenv("LNS_CONV_USE_128")) cands = {CV_L128, CV_M128, CV_S64};   // tuning knob (tile choice only)
     else cands = {CV_L64, CV_M64, CV_S64};   // 64-cout tiles at 2 waves/SIMD beat 128-cout tiles at 1 (measured)
     g.kc_log2 = conv_pick_kc_log2(k, stride, kc_log2_pack);
@@ -287,13 +287,19 @@ struct Planner {
     }
 
     // fused conv; consumes the pending transforms of `in`
+    // fuse_pack >= 0: a following 1x1 conv (64 -> 64) applied in the epilogue of this one
+    static bool can_fuse_1x1(const ConvPack& first, const ConvPack& second) {
+        static const bool off = getenv("LNS_NO_FUSE_1X1") != nullptr;
+        return !off && first.cout == 64 && second.k == 1 && second.cin == 64 && second.cout == 64;
+    }
     TRef emit_conv(const TRef& in, int pack_id, int k, int stride, int dil, const int* pad, int my, int mx,
-                   int act_out, const TRef* res, uint64_t badd, const TRef* out_forced, const std::string& name) {
+                   int act_out, const TRef* res, uint64_t badd, const TRef* out_forced, const std::string& name,
+                   int fuse_pack = -1) {
         const ConvPack& pk = e->packs[pack_id];
         if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
         const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
         ConvGeom g;
-        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1))
+        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0))
             throw std::runtime_error("no conv tiling for " + name);
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
@@ -335,13 +341,21 @@ struct Planner {
         a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
         op.flops = 2.0 * B * g.Hout * g.Wout * (double)pk.cout * pk.cin * k * k;
         op.bytes = 4.0 * B * ((double)in.C * in.H * in.W + (double)pk.cout * g.Hout * g.Wout * (res ? 2 : 1));
+        if (fuse_pack >= 0) {
+            const ConvPack& p2 = e->packs[fuse_pack];
+            if (!can_fuse_1x1(pk, p2)) throw std::runtime_error("cannot fuse 1x1 into " + name);
+            a.w2 = as_ptr<const float>(wt(p2.w_off));
+            a.bias2 = p2.has_bias ? as_ptr<const float>(wt(p2.b_off)) : nullptr;
+            a.Cout2_pad = p2.Cout_pad;
+            op.flops += 2.0 * B * g.Hout * g.Wout * 64.0 * 64.0;
+        }
         plan->ops.push_back(op);
         return out;
     }
     TRef conv_same1(const TRef& in, int pack, int act_out, const TRef* res, const TRef* out_forced,
-                    const std::string& name) {
+                    const std::string& name, int fuse_pack = -1) {
         const int pad[4] = {0, 0, 0, 0};
-        return emit_conv(in, pack, 1, 1, 1, pad, 0, 0, act_out, res, 0, out_forced, name);
+        return emit_conv(in, pack, 1, 1, 1, pad, 0, 0, act_out, res, 0, out_forced, name, fuse_pack);
     }
     TRef conv_same3(const TRef& in, int pack, int dil, int my, int mx, int act_out, const TRef* res, uint64_t badd,
                     const std::string& name) {
@@ -483,10 +497,17 @@ struct Planner {
             plan->ops.push_back(op);
         }
         arena.release(kx_off); arena.release(ky_off);
-        TRef t1 = conv_same1(uphi, l.out1, ACT_GELU, nullptr, nullptr, l.name + ".to_out.1");
-        free_t(uphi);
-        TRef out = conv_same1(t1, l.out3, ACT_NONE, &x, nullptr, l.name + ".to_out.3");
-        free_t(t1);
+        TRef out;
+        if (can_fuse_1x1(e->packs[l.out1], e->packs[l.out3])) {
+            // to_out.1 (512 -> 64, GELU) and to_out.3 (64 -> 64) + skip in ONE kernel
+            out = conv_same1(uphi, l.out1, ACT_GELU, &x, nullptr, l.name + ".to_out.1+3", l.out3);
+            free_t(uphi);
+        } else {
+            TRef t1 = conv_same1(uphi, l.out1, ACT_GELU, nullptr, nullptr, l.name + ".to_out.1");
+            free_t(uphi);
+            out = conv_same1(t1, l.out3, ACT_NONE, &x, nullptr, l.name + ".to_out.3");
+            free_t(t1);
+        }
         return out;
     }
 
@@ -634,14 +655,18 @@ struct Planner {
                 case LT_CONV: {
                     int act_out = ACT_NONE;
                     size_t skip = 0;
+                    int fuse = -1;
                     // conv -> Swish with no norm in between: fuse the activation into the epilogue
                     if (!last && L[i + 1].type == LT_SWISH) { act_out = ACT_SWISH; skip = 1; }
+                    // conv -> 1x1 conv (64 -> 64): the second conv runs in the first one's epilogue
+                    else if (!last && L[i + 1].type == LT_CONV && L[i + 1].k == 1 && L[i + 1].stride == 1 &&
+                             can_fuse_1x1(e->packs[l.pack], e->packs[L[i + 1].pack])) { fuse = L[i + 1].pack; skip = 1; }
                     const bool is_last = (i + 1 + skip == L.size());
                     nxt = emit_conv(cur, l.pack, l.k, l.stride, l.dil, l.pad, l.mode_y, l.mode_x, act_out, nullptr, 0,
-                                    is_last ? &out_ext : nullptr, l.name);
+                                    is_last ? &out_ext : nullptr, fuse >= 0 ? L[i + 1].name : l.name, fuse);
                     free_t(cur);
                     i += skip;
-                    if (!is_last) trace(l.name, nxt);
+                    if (!is_last) trace(fuse >= 0 ? L[i].name : l.name, nxt);   // i already points at the fused 1x1
                     break;
                 }
                 case LT_SWISH:
@@ -838,7 +863,7 @@ struct Runner {
                 case OP_CONV: {
                     ConvArgs a = op.conv;
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
-                    fix(a.y, B); fix(a.res, B); fix(a.badd, B);
+                    fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B);
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
                     rc = launch_conv(op.variant, a, stream);
                     break;

@@ -36,6 +36,9 @@ struct ConvArgs {
     int PH, PW;            // staged patch extent
     unsigned ph_magic;     // ceil(2^32 / PH), 0 when PH == 1
     int vec4;              // 1x1 only: 16-byte patch loads (HW % 4 == 0, 16-byte aligned bases)
+    // optional fused second 1x1 conv (Cout -> Cout, Cout == tile height 64): applied after act_out,
+    // before the residual add.  w2: packed [Cout][Cout2_pad] slab of the 1x1 weight, bias2 [Cout].
+    const float* w2; const float* bias2; int Cout2_pad;
     int B;
 };
 

@@ -75,7 +75,9 @@ __device__ __forceinline__ float swish_fast(float v) {
 // KCL = channels per LDS stage (3x3: 4 or 8, 1x1: 16).  The MFMA loop always walks a stage in
 // sub-stages of KORD channels (3x3: 4, 1x1: 16), tap-major inside a sub-stage, so the fp32
 // accumulation ORDER of an output is the same for every KCL / tile variant / batch.
-template <int MT, int NT, int WGM, int WGN, int KS, bool VEC, int KCL>
+// FUSE2: a second, 1x1 convolution (TM -> TM channels, bias) is applied to the tile in the epilogue
+// (needs WGM == 1 and Cout == TM, i.e. every wave holds all channels of its pixels).
+template <int MT, int NT, int WGM, int WGN, int KS, bool VEC, int KCL, bool FUSE2 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int TM = WGM * MT * 32;
@@ -361,6 +363,45 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
     }
+    // Fused second 1x1 convolution: Y2[co2][px] = sum_co W2[co2][co] * Y1[co][px] + bias2[co2].
+    // The accumulator tile Y1 (rows = channels in registers, pixels on lanes) is exactly the B
+    // operand layout of the next MFMA when the contraction runs over its ROW index: k-step r of
+    // channel block mt takes accumulator register r (lanes kh=0 supply row drow(r,0), kh=1 row
+    // drow(r,1)); the A operand W2 (LDS, [k][co2] = the packed 1x1 weight slab) is fetched in the
+    // matching permuted k order.  Y1 never leaves registers.
+    if (FUSE2) {
+        static_assert(!FUSE2 || WGM == 1, "fused 1x1 needs all channels of a pixel in one wave");
+        float* W2s = lds;                                   // the stage buffers are free now
+        __syncthreads();
+        for (int i = tid; i < TM * TM / 4; i += NTHR) {
+            const int k = i / (TM / 4), c4 = i - k * (TM / 4);
+            *reinterpret_cast<float4*>(W2s + k * TM + c4 * 4) =
+                *reinterpret_cast<const float4*>(a.w2 + (long)k * a.Cout2_pad + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc2[MT];
+#pragma unroll
+            for (int m2 = 0; m2 < MT; ++m2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[m2][r] = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            W2s[(mt * 32 + drow(r, kh)) * TM + m2 * 32 + l31], acc[mt][nt][r], acc2[m2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < MT; ++m2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co2 = m2 * 32 + drow(r, kh);
+                    acc[m2][nt][r] = acc2[m2][r] + (a.bias2 ? a.bias2[co2] : 0.0f);
+                }
+        }
+    }
     // stores: row r of a tile is cout cob + (r&3) + 8*(r>>2); 128-byte pixel runs per half-wave.
     // Offsets from one per-(mt,nt) base pointer are multiples of HWo (uniform scalars).
 #pragma unroll
@@ -443,6 +484,17 @@ template <int MT, int NT, int WGM, int WGN>
 static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
     dim3 blk(64 * WGM * WGN);
+    if (a.w2) {
+        if constexpr (WGM == 1 && MT == 2) {
+            if (a.ks == 3 && a.kc_log2 == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false, 8, true>), grid, blk, lds, s, a);
+            else if (a.ks == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false, 4, true>), grid, blk, lds, s, a);
+            else if (a.vec4) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, true, 16, true>), grid, blk, lds, s, a);
+            else hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, false, 16, true>), grid, blk, lds, s, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (a.ks == 3 && a.kc_log2 == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false, 8>), grid, blk, lds, s, a);
     else if (a.ks == 3) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 3, false, 4>), grid, blk, lds, s, a);
     else if (a.vec4) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WGM, WGN, 1, true, 16>), grid, blk, lds, s, a);
@@ -1353,6 +1405,10 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, true, 16>))
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, false, 16>))
     LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false, 4, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false, 8, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, true, 16, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, false, 16, true>))
     LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 3, false, 8>))
     LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, true, 16>))
     LNS_SET_LDS((conv_mfma_kernel<2, 2, 1, 4, 1, false, 16>))
@@ -1361,6 +1417,10 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, true, 16>))
     LNS_SET_LDS((conv_mfma_kernel<2, 2, 2, 2, 1, false, 16>))
     LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false, 4>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false, 4, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false, 8, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, true, 16, true>))
+    LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, false, 16, true>))
     LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 3, false, 8>))
     LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, true, 16>))
     LNS_SET_LDS((conv_mfma_kernel<2, 1, 1, 4, 1, false, 16>))

@@ -99,7 +99,8 @@ static void pack_conv_weight(float* dst, const float* src, int cout_off, int cou
 struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Hout, Wout, kc_log2, sel_kc_log2; };
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
-                          int kc_log2_pack, int Cout_pad, int force_variant, bool need_wgm1 = false) {
+                          int kc_log2_pack, int Cout_pad, int force_variant, bool need_wgm1 = false,
+                          bool allow_bf16x3 = false) {
     g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
     g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
     if (g.Hout <= 0 || g.Wout <= 0) return false;
@@ -109,6 +110,14 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
     else if (Cout <= 64) cands = need_wgm1 ? std::vector<int>{CV_L64, CV_M64} : std::vector<int>{CV_L64, CV_M64, CV_S64};
     else if (getenv("LNS_CONV_USE_128")) cands = {CV_L128, CV_M128, CV_S64};   // tuning knob (tile choice only)
     else cands = {CV_L64, CV_M64, CV_S64};   // 64-cout tiles at 2 waves/SIMD beat 128-cout tiles at 1 (measured)
+    // bf16x3 kernel for every eligible 3x3 conv.  Eligibility is a function of the layer only (never of B):
+    // the fp32 variants accumulate in a different order, and a trajectory must not change bitwise with the
+    // batch it is computed in.
+    static const bool no_bf16x3 = getenv("LNS_CONV_FP32_MFMA") != nullptr;
+    const bool use_b = allow_bf16x3 && !no_bf16x3 && k == 3 && stride == 1 && Cout > 32;
+    if (force_variant < 0 && use_b) {   // fp32 variants only if the geometry rules the bf16x3 tiles out
+        cands.insert(cands.begin(), (int)CV_B64);
+    }
     g.kc_log2 = conv_pick_kc_log2(k, stride, kc_log2_pack);
     static const int pref[] = {5, 6, 4, 7, 3, 8};   // log2 BW preference on ties: 32,64,16,128,8,256
     bool found = false;
@@ -118,6 +127,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         ConvArgs tmp;
         memset(&tmp, 0, sizeof tmp);
         tmp.ks = k; tmp.kc_log2 = g.kc_log2; tmp.Cin_pad = 1 << kc_log2_pack;
+        if (cands[ci] == CV_B64) { tmp.stride = stride; tmp.Cin_pad = 512; tmp.wb = &tmp; }
         int best_bw = -1, txn = 0, tyn = 0, best_kc = g.kc_log2;
         if (k == 1) {
             // 1x1: the image is a flat array of H*W pixels, a tile is TN consecutive pixels
@@ -138,7 +148,11 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
                 tmp.PH = (BH - 1) * stride + (k - 1) * dil + 1;
                 tmp.PW = (BW - 1) * stride + (k - 1) * dil + 1;
                 tmp.kc_log2 = g.kc_log2;
-                if (!conv_fits(cands[ci], tmp)) { tmp.kc_log2 = 2; if (!conv_fits(cands[ci], tmp)) continue; }
+                if (!conv_fits(cands[ci], tmp)) {
+                    if (cands[ci] == CV_B64) continue;
+                    tmp.kc_log2 = 2;
+                    if (!conv_fits(cands[ci], tmp)) continue;
+                }
                 if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bw = lb; best_kc = tmp.kc_log2; }
             }
             if (best_bw < 0) continue;
@@ -153,6 +167,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         g.PH = tmp.PH; g.PW = tmp.PW; g.sel_kc_log2 = best_kc;
         found = true;
         static const long min_blocks = getenv("LNS_CONV_MIN_BLOCKS") ? atol(getenv("LNS_CONV_MIN_BLOCKS")) : 128;
+        if (cands[ci] == CV_B64) break;                        // never fall through to fp32 by launch size
         if (blocks >= min_blocks) break;
     }
     return found;
@@ -299,7 +314,7 @@ struct Planner {
         if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
         const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
         ConvGeom g;
-        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0))
+        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb))
             throw std::runtime_error("no conv tiling for " + name);
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
@@ -322,6 +337,7 @@ struct Planner {
         memset(&a, 0, sizeof a);
         a.x = as_ptr<const float>(in.ptr); a.x_bs = in.bs; a.Cin = in.C; a.Hin = in.H; a.Win = in.W;
         a.w = as_ptr<const float>(wt(pk.w_off));
+        if (g.variant == CV_B64) a.wb = as_ptr<const void>(wt(pk.wb_off));
         a.bias = pk.has_bias ? as_ptr<const float>(wt(pk.b_off)) : nullptr;
         a.ss = as_ptr<const float>(in.ss);
         a.act_in = in.act; a.act_out = act_out;
@@ -729,6 +745,8 @@ static int finalize_weights(lns_engine* e, int device) {
     for (ConvPack& p : e->packs) {
         p.w_off = off; off += round_up_sz((size_t)p.k * p.k * p.Cin_pad * p.Cout_pad, 64);
         p.b_off = off; off += round_up_sz((size_t)p.Cout_pad, 64);
+        p.has_wb = p.k == 3 && p.Cin_pad % 8 == 0 && p.cout > 32;
+        if (p.has_wb) { p.wb_off = off; off += round_up_sz(convb_weight_bytes(p.cout, p.Cin_pad) / 4, 64); }
     }
     for (VecPack& v : e->vecs) { v.off = off; off += round_up_sz(v.count, 64); }
     std::vector<float> host(off, 0.0f);
@@ -737,6 +755,7 @@ static int finalize_weights(lns_engine* e, int device) {
         for (size_t i = 0; i < p.wkeys.size(); ++i) {
             const Param& w = e->params[e->pindex.at(p.wkeys[i])];
             pack_conv_weight(host.data() + p.w_off, w.host.data(), co, p.couts[i], p.cin, p.k, p.Cin_pad, p.Cout_pad);
+            if (p.has_wb) convb_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
             if (!p.bkeys[i].empty()) {
                 const Param& b = e->params[e->pindex.at(p.bkeys[i])];
                 memcpy(host.data() + p.b_off + co, b.host.data(), (size_t)p.couts[i] * 4);
@@ -863,7 +882,7 @@ struct Runner {
                 case OP_CONV: {
                     ConvArgs a = op.conv;
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
-                    fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B);
+                    fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B);
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
                     rc = launch_conv(op.variant, a, stream);
                     break;
@@ -1396,6 +1415,11 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     std::vector<float> hw(wcount + pk.Cout_pad, 0.0f);
     pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
     if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
+    const size_t wb_floats = g.variant == CV_B64 ? convb_weight_bytes(Cout, pk.Cin_pad) / 4 : 0;
+    if (wb_floats) {
+        hw.resize(hw.size() + wb_floats, 0.0f);
+        convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
+    }
     float* dw = nullptr; int* dmaps = nullptr;
     OPCHK(hipMalloc(reinterpret_cast<void**>(&dw), hw.size() * 4));
     OPCHK(hipMalloc(reinterpret_cast<void**>(&dmaps), (rm.size() + cm.size()) * 4));
@@ -1406,6 +1430,7 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     memset(&a, 0, sizeof a);
     a.x = x; a.x_bs = (long)Cin * Hin * Win; a.Cin = Cin; a.Hin = Hin; a.Win = Win;
     a.w = dw; a.bias = bias_host ? dw + wcount : nullptr; a.ss = ss; a.act_in = act_in; a.act_out = act_out;
+    if (wb_floats) a.wb = dw + wcount + pk.Cout_pad;
     a.rowmap = dmaps; a.colmap = dmaps + rm.size();
     a.vec4 = (ksize == 1 && ((Hin * Win) % 4 == 0)) ? 1 : 0;
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;

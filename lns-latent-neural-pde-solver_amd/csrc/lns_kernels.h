@@ -39,17 +39,30 @@ struct ConvArgs {
     // optional fused second 1x1 conv (Cout -> Cout, Cout == tile height 64): applied after act_out,
     // before the residual add.  w2: packed [Cout][Cout2_pad] slab of the 1x1 weight, bias2 [Cout].
     const float* w2; const float* bias2; int Cout2_pad;
+    // bf16x3 path (3x3, stride 1): weights pre-split into 3 bf16 terms,
+    // layout [cout tile][stage of 8 ch][split 3][tap pair 5][k half 2][64 cout][8 ch]
+    const void* wb;
     int B;
 };
 
 // tile variants: (TM couts x TN pixels) per 256-thread block
-enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4, CV_S32 = 5, CV_COUNT = 6 };
+enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4, CV_S32 = 5, CV_COUNT = 6,
+                   CV_B64 = 6 /* bf16x3 3x3 kernel, 64 couts x 128 pixels */ };
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
 size_t conv_lds_bytes(int variant, const ConvArgs& a);
 int conv_pick_kc_log2(int ks, int stride, int kc_log2_max);
 bool conv_fits(int variant, const ConvArgs& a);
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
+// 3x3 convolution on bf16 MFMA with every fp32 operand split into three bf16 terms (6 products,
+// two accumulators): fp32-level accuracy at 2.7x the fp32-MFMA rate.  Tile 64 couts x 128 pixels.
+#define CONVB_SLAB_BYTES 30720           // one (cout tile, stage) weight slab
+size_t convb_lds_bytes(const ConvArgs& a);
+bool convb_fits(const ConvArgs& a);
+hipError_t launch_conv_bf16x3(const ConvArgs& a, hipStream_t s);
+// host-side packing of one [Cout][Cin][3][3] weight (cout offset co0 inside the pack) into the bf16x3 slab layout
+size_t convb_weight_bytes(int Cout, int Cin_pad);
+void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);
 
 // ---------------------------------------------------------------------------
 // GroupNorm statistics -> per-(b,c) scale/shift (fused into the consumer conv)

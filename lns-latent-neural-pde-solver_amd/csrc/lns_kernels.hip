@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 static const ConvVariantInfo kConvInfo[CV_COUNT] = {
     {128, 256}, {64, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 128}};
 
-ConvVariantInfo conv_variant_info(int v) { return kConvInfo[v]; }
+ConvVariantInfo conv_variant_info(int v) { return v == CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v]; }
 
 // Stage depth (channels per LDS stage).  It is a function of the kernel size ONLY
 // (3x3: 4, 1x1: 16), never of the tile variant or batch: the fp32
@@ -464,6 +464,7 @@ int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
 static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8 : CONV_MAXE3) : CONV_MAXE1; }
 
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
+    if (variant == CV_B64) return convb_lds_bytes(a);
     const int KC = 1 << a.kc_log2;
     const int TM = kConvInfo[variant].TM;
     const size_t xs = (size_t)conv_maxe(a.ks, KC) * 256;
@@ -472,6 +473,7 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 }
 
 bool conv_fits(int variant, const ConvArgs& a) {
+    if (variant == CV_B64) return convb_fits(a);
     const long KC = 1 << a.kc_log2;
     const int TN = kConvInfo[variant].TN;
     if (a.ks == 3 ? (KC != 4 && KC != 8) : (KC != 16)) return false;
@@ -503,6 +505,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 }
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
+    if (variant == CV_B64) return launch_conv_bf16x3(a, s);
     if (!conv_fits(variant, a)) return hipErrorInvalidValue;
     const size_t lds = conv_lds_bytes(variant, a);
     switch (variant) {
@@ -514,6 +517,393 @@ hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
         case CV_S32: return launch_conv_t<1, 1, 1, 4>(a, lds, s);
     }
     return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// 3x3 convolution on the bf16 matrix pipe with fp32-level accuracy ("bf16x3").
+// Every fp32 operand x is split into three bf16 terms x = h + m + l (24 significant bits);
+// x*y ~= hh' + [hm' + mh' + hl' + lh' + mm'] (the dropped terms are <= 2^-23 |xy|).  bf16 x bf16
+// products are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result
+// matches an fp32 GEMM to rounding.  The hh' terms go to one accumulator (the same K-long fp32
+// chain as the fp32 kernel), the five small terms to a second one (their rounding errors are
+// 2^-8 smaller), summed once in the epilogue.  6 bf16 MFMAs (32 cycles, K=16) replace 8 fp32
+// MFMAs (64 cycles, K=2): 2.7x the fp32-MFMA rate.
+//   tile  : 64 couts x 128 pixels (NT=1), 4 waves, wave = 64 couts x 32 pixels, 2 waves/SIMD.
+//           The 256-pixel shape (NT=2: 344 registers, 1 wave/SIMD, 95 KB LDS) measured slower on
+//           every layer mix (15.5k vs 16.4k trajectory-steps/s) and is not instantiated -- see DESIGN.md.
+//   stage : 8 input channels; MFMA K=16 = 2 taps x 8 channels (9 taps padded to 10)
+//   LDS   : patch  [split][pixel][8 ch] bf16 (16-byte units: conflict-free b128 reads),
+//           weights [split][tap pair][k half][cout][8 ch] bf16 (straight copy of the host slab)
+//   same software pipeline as the fp32 kernel (register prefetch two stages ahead, staging
+//   interleaved with the MFMA steps, one barrier per stage); prologue transform, padding maps,
+//   epilogue (bias / act / fused 1x1 / residual) identical.
+// ===========================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define CONVB_MAXU 3      // patch units (pixel x 8 channels) per thread per stage
+#define CONVB_NWU 8       // weight 16-byte units per thread per stage (1920 per slab)
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float x, float y) {      // v_cvt_pk_bf16_f32 (RNE)
+    f32x2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// two fp32 values -> packed (h, m, l) bf16 pairs with x = h + m + l to 24 bits
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(x, y);
+    const float rx = x - __uint_as_float(h << 16), ry = y - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(rx, ry);
+    l = pk_bf16(rx - __uint_as_float(m << 16), ry - __uint_as_float(m & 0xffff0000u));
+}
+
+template <int NT, bool FUSE2>
+__global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
+    constexpr int NTHR = 256, TM = 64, TN = 128 * NT, MT = 2, KC = 8, NJ = 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int PH = a.PH, PW = a.PW;
+    const int PLANE = PH * PW;
+    const int PPAD = (PLANE + 3) & ~3;
+    const int xb_bytes = 3 * PPAD * 16;
+    const int buf_bytes = xb_bytes + CONVB_SLAB_BYTES;
+    char* lds = smem;                                                  // 2 x [Xb | Wb]
+    float* ssl = reinterpret_cast<float*>(lds + 2 * buf_bytes);        // [Cin_pad][2]
+    int* rmap = reinterpret_cast<int*>(ssl + a.Cin_pad * 2);
+    int* cmap = rmap + PH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.y;
+    int bid = blockIdx.x;
+    const int ct = bid % a.cout_tiles;
+    bid /= a.cout_tiles;
+    const int tx = bid % a.tiles_x, ty = bid / a.tiles_x;
+    const int BW = 1 << a.bw_log2, BH = TN >> a.bw_log2;
+    const int HWin = a.Hin * a.Win;
+    const float* xb = a.x + (long)b * a.x_bs;
+    const bool has_ss = a.ss != nullptr;
+    const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
+
+    for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
+        ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+    for (int i = tid; i < PH; i += NTHR) rmap[i] = a.rowmap[ty * BH * a.stride + i];
+    for (int i = tid; i < PW; i += NTHR) cmap[i] = a.colmap[tx * BW * a.stride + i];
+    __syncthreads();
+
+    // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or -1
+    int udesc[CONVB_MAXU];
+    const int nunit = (PLANE + NTHR - 1) / NTHR;
+#pragma unroll
+    for (int u = 0; u < CONVB_MAXU; ++u) {
+        const int p = tid + u * NTHR;
+        int d = -1;
+        if (p < PLANE) {
+            const int py = p / PW, px = p - py * PW;
+            const int sy = rmap[py], sx = cmap[px];
+            if (sy >= 0 && sx >= 0) d = sy * a.Win + sx;
+        }
+        udesc[u] = d;
+    }
+    // weight slab of this cout tile: CONVB_SLAB_BYTES per stage, copied 16 bytes per thread-slot
+    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)ct * (a.Cin_pad / KC) * CONVB_SLAB_BYTES;
+
+    int boff[NT], ltoff[NJ];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = (wn * NT + nt) * 32 + l31;
+        boff[nt] = ((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = 2 * j + kh;                       // this lane half's tap in k-step j (tap 9 = zero pad)
+        ltoff[j] = t < 9 ? ((t / 3) * a.dil) * PW + (t % 3) * a.dil : 0;
+    }
+
+    f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc_hi[mt][nt][r] = 0.0f; acc_lo[mt][nt][r] = 0.0f; }
+
+    float pv[CONVB_MAXU][KC];
+    float wq[CONVB_NWU][4];
+
+    auto load_unit = [&](int u, int c0) __attribute__((always_inline)) {
+        const int d = udesc[u];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const bool ok = d >= 0 && (c0 + c) < a.Cin;
+            const float* src = ok ? xb + ((long)(c0 + c) * HWin + d) : xb;
+            pv[u][c] = *src;
+        }
+    };
+    auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
+        const int idx = tid + i * NTHR;                  // 16-byte unit inside the slab
+        const int off = idx < CONVB_SLAB_BYTES / 16 ? idx : 0;
+        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB_SLAB_BYTES + (long)off * 16);
+        wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
+    };
+    auto write_unit = [&](auto mode_tag, int u, int c0, char* Xn) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const int p = tid + u * NTHR;
+        const int d = udesc[u];
+        uint4 vh, vm, vl;
+        float t[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            float v = pv[u][c];
+            if (MODE >= 1) { const float2 st = *reinterpret_cast<const float2*>(ssl + 2 * (c0 + c)); v = v * st.x + st.y; }
+            if (MODE == 2) v = swish_fast(v);
+            t[c] = (d >= 0 && (c0 + c) < a.Cin) ? v : 0.0f;
+        }
+        split3_pair(t[0], t[1], vh.x, vm.x, vl.x);
+        split3_pair(t[2], t[3], vh.y, vm.y, vl.y);
+        split3_pair(t[4], t[5], vh.z, vm.z, vl.z);
+        split3_pair(t[6], t[7], vh.w, vm.w, vl.w);
+        if (p < PPAD) {
+            *reinterpret_cast<uint4*>(Xn + ((long)(0 * PPAD + p)) * 16) = vh;
+            *reinterpret_cast<uint4*>(Xn + ((long)(1 * PPAD + p)) * 16) = vm;
+            *reinterpret_cast<uint4*>(Xn + ((long)(2 * PPAD + p)) * 16) = vl;
+        }
+    };
+    auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
+        const int idx = tid + i * NTHR;
+        if (idx < CONVB_SLAB_BYTES / 16)
+            *reinterpret_cast<float4*>(Wn + (long)idx * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
+    };
+
+    // fragments of k-step j: A[s][mt] (couts), B[s][nt] (pixels), s = h / m / l
+    auto load_frags = [&](int j, const char* Xs, const char* Ws, bf16x8 (&af)[3][MT], bf16x8 (&bf)[3][NT])
+                          __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                af[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + ((((s * NJ + j) * 2 + kh) * TM) + mt * 32 + l31) * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bf[s][nt] = *reinterpret_cast<const bf16x8*>(Xs + ((long)(s * PPAD + boff[nt] + ltoff[j])) * 16);
+        }
+    };
+
+    auto k_loop = [&](auto mode_tag) __attribute__((always_inline)) {
+        const int last = a.Cin_pad - KC;
+        constexpr int NSLOT = CONVB_MAXU + CONVB_NWU;
+#pragma unroll
+        for (int u = 0; u < CONVB_MAXU; ++u) if (u < nunit) load_unit(u, 0);
+#pragma unroll
+        for (int i = 0; i < CONVB_NWU; ++i) load_w(i, 0);
+#pragma unroll
+        for (int u = 0; u < CONVB_MAXU; ++u) if (u < nunit) write_unit(mode_tag, u, 0, lds);
+#pragma unroll
+        for (int i = 0; i < CONVB_NWU; ++i) write_w(i, lds + xb_bytes);
+        {
+            const int c1 = KC < last ? KC : last;
+#pragma unroll
+            for (int u = 0; u < CONVB_MAXU; ++u) if (u < nunit) load_unit(u, c1);
+#pragma unroll
+            for (int i = 0; i < CONVB_NWU; ++i) load_w(i, c1);
+        }
+        __syncthreads();
+        int buf = 0;
+        for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
+            const char* Xs = lds + buf * buf_bytes;
+            const char* Ws = Xs + xb_bytes;
+            char* Xn = lds + (buf ^ 1) * buf_bytes;
+            char* Wn = Xn + xb_bytes;
+            const int cw = c0 + KC < last ? c0 + KC : last;
+            const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
+            bf16x8 af[2][3][MT], bf[2][3][NT];
+            load_frags(0, Xs, Ws, af[0], bf[0]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 1 < NJ) load_frags(j + 1, Xs, Ws, af[(j + 1) & 1], bf[(j + 1) & 1]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        auto& A = af[j & 1];
+                        auto& Bq = bf[j & 1];
+                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bq[1][nt], acc_lo[mt][nt], 0, 0, 0);
+                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bq[2][nt], acc_lo[mt][nt], 0, 0, 0);
+                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], Bq[0][nt], acc_lo[mt][nt], 0, 0, 0);
+                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bq[1][nt], acc_lo[mt][nt], 0, 0, 0);
+                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bq[0][nt], acc_lo[mt][nt], 0, 0, 0);
+                        acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bq[0][nt], acc_hi[mt][nt], 0, 0, 0);
+                    }
+                // staging slots spread over the k-steps: 11 slots over 5 steps
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) {
+                    const int q = j * 3 + qq;
+                    if (q >= NSLOT) continue;
+                    if (q < CONVB_MAXU) {
+                        if (q < nunit) { write_unit(mode_tag, q, cw, Xn); load_unit(q, cl2); }
+                    } else {
+                        write_w(q - CONVB_MAXU, Wn);
+                        load_w(q - CONVB_MAXU, cl2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    };
+    if (pro_mode == 2) k_loop(std::integral_constant<int, 2>{});
+    else if (pro_mode == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
+
+    // ---- epilogue (fp32) ---------------------------------------------------------
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc_hi[mt][nt][r] + acc_lo[mt][nt][r];
+    const int HWo = a.Hout * a.Wout;
+    float* yb = a.y + (long)b * a.y_bs;
+    const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+    if (a.bias || a.badd) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int cob = ct * TM + mt * 32 + 4 * kh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                const int cc = co < a.Cout ? co : 0;
+                float add = 0.0f;
+                if (a.bias) add += a.bias[cc];
+                if (a.badd) add += a.badd[(long)b * a.Cout + cc];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
+            }
+        }
+    }
+    if (a.act_out == ACT_GELU) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_apply(acc[mt][nt][r], ACT_GELU);
+    } else if (a.act_out == ACT_SWISH) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
+    }
+    if (FUSE2) {   // second 1x1 conv in fp32 (see conv_mfma_kernel): the accumulator tile is the B operand
+        float* W2s = reinterpret_cast<float*>(lds);
+        __syncthreads();
+        for (int i = tid; i < TM * TM / 4; i += NTHR) {
+            const int k = i / (TM / 4), c4 = i - k * (TM / 4);
+            *reinterpret_cast<float4*>(W2s + k * TM + c4 * 4) =
+                *reinterpret_cast<const float4*>(a.w2 + (long)k * a.Cout2_pad + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc2[MT];
+#pragma unroll
+            for (int m2 = 0; m2 < MT; ++m2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[m2][r] = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            W2s[(mt * 32 + drow(r, kh)) * TM + m2 * 32 + l31], acc[mt][nt][r], acc2[m2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < MT; ++m2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[m2][nt][r] = acc2[m2][r] + (a.bias2 ? a.bias2[m2 * 32 + drow(r, kh)] : 0.0f);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = (wn * NT + nt) * 32 + l31;
+        const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
+        if (!((oy < a.Hout) && (ox < a.Wout))) continue;
+        const int pix = oy * a.Wout + ox;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int cob = ct * TM + mt * 32 + 4 * kh;
+            float* yp = yb + ((long)cob * HWo + pix);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                if (co < a.Cout) {
+                    const int ro = ((r & 3) + 8 * (r >> 2)) * HWo;
+                    float v = acc[mt][nt][r];
+                    if (rb) v += rb[(long)cob * HWo + pix + ro];
+                    yp[ro] = v;
+                }
+            }
+        }
+    }
+}
+
+size_t convb_lds_bytes(const ConvArgs& a) {
+    const size_t ppad = ((size_t)a.PH * a.PW + 3) & ~(size_t)3;
+    return 2 * (3 * ppad * 16 + CONVB_SLAB_BYTES) + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
+}
+
+bool convb_fits(const ConvArgs& a) {
+    return a.ks == 3 && a.stride == 1 && (a.Cin_pad % 8) == 0 && a.wb != nullptr &&
+           (long)a.PH * a.PW <= CONVB_MAXU * 256 && convb_lds_bytes(a) <= 150 * 1024;
+}
+
+size_t convb_weight_bytes(int Cout, int Cin_pad) {
+    return (size_t)((Cout + 63) / 64) * (Cin_pad / 8) * CONVB_SLAB_BYTES;
+}
+
+static inline uint16_t host_bf16_rne(float x, float* back) {
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    __builtin_memcpy(back, &u, 4);
+    return (uint16_t)(u >> 16);
+}
+
+void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad) {
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    const int nstage = Cin_pad / 8;
+    for (int co = 0; co < cout; ++co) {
+        const int cog = co0 + co, ct = cog / 64, cl = cog % 64;
+        for (int ci = 0; ci < cin; ++ci) {
+            const int st = ci / 8, c = ci % 8;
+            for (int t = 0; t < 9; ++t) {
+                const float v = w[((size_t)co * cin + ci) * 9 + t];
+                float hb, mb, lb;
+                uint16_t q[3];
+                q[0] = host_bf16_rne(v, &hb);
+                q[1] = host_bf16_rne(v - hb, &mb);
+                q[2] = host_bf16_rne((v - hb) - mb, &lb);
+                const int j = t / 2, kh = t % 2;
+                for (int sidx = 0; sidx < 3; ++sidx) {
+                    const size_t unit = ((((size_t)ct * nstage + st) * 3 + sidx) * 5 + j) * 2 + kh;
+                    d[(unit * 64 + cl) * 8 + c] = q[sidx];
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_conv_bf16x3(const ConvArgs& a, hipStream_t s) {
+    if (!convb_fits(a)) return hipErrorInvalidValue;
+    dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
+    const size_t lds = convb_lds_bytes(a);
+    if (a.w2) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, false>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
 }
 
 // ===========================================================================
@@ -1442,6 +1832,8 @@ hipError_t init_kernels() {
     LNS_SET_LDS((fa_sandwich_kernel<2, 3, false>))
     LNS_SET_LDS((fa_sandwich_kernel<2, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<2, 1, false>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, false>))
     LNS_SET_LDS(fa_lrk_kernel)
     LNS_SET_LDS(fa_pool_kernel)
     LNS_SET_LDS(fa_reducer_kernel)

@@ -111,6 +111,15 @@ CONV_CASES = [
     dict(B=3, Cin=64, Cout=2048, H=1, W=64, k=1, bias=False),
     dict(B=1, Cin=32, Cout=32, H=8, W=8, k=3, mode=(1, 1)),
 ]
+# bf16x3 kernel (variant 6): every stride-1 3x3 shape class, prologue / epilogue features included
+for _c in [dict(B=2, Cin=64, Cout=64, H=32, W=32, mode=(1, 1)), dict(B=2, Cin=64, Cout=64, H=24, W=48, mode=(0, 1)),
+           dict(B=2, Cin=128, Cout=128, H=16, W=16, dil=2, mode=(1, 1)), dict(B=2, Cin=128, Cout=128, H=12, W=24, dil=3, mode=(0, 1)),
+           dict(B=2, Cin=128, Cout=128, H=7, W=15, dil=2, mode=(0, 0)), dict(B=2, Cin=64, Cout=64, H=16, W=16, up=(32, 32), mode=(1, 1)),
+           dict(B=2, Cin=64, Cout=64, H=28, W=60, up=(61, 121), mode=(0, 0)),
+           dict(B=2, Cin=64, Cout=128, H=32, W=32, ss=True, act_in=1, res=True),
+           dict(B=2, Cin=128, Cout=128, H=16, W=16, ss=True, act_in=1, act_out=2, badd=True),
+           dict(B=2, Cin=40, Cout=72, H=20, W=36, mode=(0, 0)), dict(B=1, Cin=512, Cout=64, H=32, W=32, mode=(1, 1), ss=True)]:
+    CONV_CASES.append(dict(k=3, variant=6, **_c))
 for _v in range(6):   # every tile variant on the same problem
     CONV_CASES.append(dict(B=2, Cin=64, Cout=(32 if _v == 5 else 128 if _v in (0, 2) else 64), H=32, W=32, k=3,
                            mode=(1, 1), variant=_v))

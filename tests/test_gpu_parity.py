@@ -177,6 +177,26 @@ def test_module_api_surface():
     assert not torch.equal(model.propagator(z), z1)
 
 
+def test_overlapped_rollout_equals_single_stream():
+    """The multi-stream rollout (propagator stream + decode streams, kernels of different steps co-resident
+    on the CUs) must reproduce the single-stream rollout bit for bit at the bench batch size."""
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    args = config.preset("ns2d_128")
+    model, _ = gc.build_models(args, 1)
+    x = filler.normal("xfull", (64, args.in_channels, args.Ly, args.Lx), 5)
+    xd = torch.from_numpy(x).cuda()
+    eng = model._engine(xd)
+    eng.timing_enable(True)            # diagnostics mode = everything on the caller's stream
+    ref = model.predict(xd, 6, to_x=True).clone()
+    eng.timing_enable(False)
+    for _ in range(3):
+        y = model.predict(xd, 6, to_x=True)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+
+
 def test_full_size_rollout_properties():
     """BASELINE config 2 shape (B=64, T=64 is the bench; here T=4 to bound memory/time):
     finite, per-sample independent (bitwise) and close to the oracle on a sub-batch."""

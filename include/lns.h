@@ -182,6 +182,13 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
                   int dilation, int pad_t, int pad_b, int pad_l, int pad_r, int mode_y, int mode_x,
                   const float* ss, int act_in, int act_out, const float* residual,
                   const float* badd, float* y, int tile_variant, void* stream);
+/* Diagnostic: runs two convolutions (GroupNorm+Swish prologue, circular padding, stride 1) repeatedly on two HIP
+ * streams so that their workgroups share compute units, and counts output words that differ from what each
+ * convolution produces alone.  variant_*: tile variant as in lns_op_conv2d (-1 automatic, 6 = bf16x3 3x3 kernel). */
+int lns_op_conv_pair_stress(int B, int H, int W, int cin_a, int cout_a, int ksize_a, int variant_a, int cin_b, int cout_b,
+                            int ksize_b, int variant_b, int rounds, int launches, long long* mismatches_a,
+                            long long* mismatches_b);
+
 /* GroupNorm statistics -> per-(b,c) (scale,shift) such that norm(x) = x*scale+shift. */
 int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, float eps,
                            const float* gamma_host, const float* beta_host, const float* premul,

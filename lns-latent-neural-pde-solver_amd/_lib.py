@@ -60,7 +60,7 @@ SYMBOLS = [
     "lns_encode", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent",
     "lns_trace_enable", "lns_trace_count", "lns_trace_info", "lns_trace_copy",
     "lns_timing_enable", "lns_timing_count", "lns_timing_info",
-    "lns_op_conv2d", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block",
+    "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block",
 ]
 
 _lib = None

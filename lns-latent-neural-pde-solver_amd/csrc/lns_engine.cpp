@@ -1383,10 +1383,19 @@ static thread_local std::string g_op_error;
     do { hipError_t err__ = (call);                                                                   \
          if (err__ != hipSuccess) { g_op_error = fmt("%s: %s", #call, hipGetErrorString(err__)); fprintf(stderr, "lns_op: %s\n", g_op_error.c_str()); return LNS_EHIP; } } while (0)
 
-int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv, const float* w_host,
-                  const float* bias_host, int Cout, int ksize, int stride, int dilation, int pad_t, int pad_b, int pad_l,
-                  int pad_r, int mode_y, int mode_x, const float* ss, int act_in, int act_out, const float* residual,
-                  const float* badd, float* y, int tile_variant, void* stream) {
+// a conv launch prepared from host weights (device buffers owned by the struct)
+struct OpConv {
+    ConvArgs a;
+    int variant = -1;
+    float* dw = nullptr;
+    int* dmaps = nullptr;
+    void release() { (void)hipFree(dw); (void)hipFree(dmaps); dw = nullptr; dmaps = nullptr; }
+};
+
+static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv,
+                           const float* w_host, const float* bias_host, int Cout, int ksize, int stride, int dilation,
+                           int pad_t, int pad_b, int pad_l, int pad_r, int mode_y, int mode_x, const float* ss, int act_in,
+                           int act_out, const float* residual, const float* badd, float* y, int tile_variant) {
     if (!x || !w_host || !y || (ksize != 1 && ksize != 3)) return LNS_EINVAL;
     if (act_in != ACT_NONE && act_in != ACT_SWISH) return LNS_EINVAL;   // prologue: GroupNorm scale/shift + Swish only
     OPCHK(init_kernels());
@@ -1420,18 +1429,17 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
         hw.resize(hw.size() + wb_floats, 0.0f);
         convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
     }
-    float* dw = nullptr; int* dmaps = nullptr;
-    OPCHK(hipMalloc(reinterpret_cast<void**>(&dw), hw.size() * 4));
-    OPCHK(hipMalloc(reinterpret_cast<void**>(&dmaps), (rm.size() + cm.size()) * 4));
-    OPCHK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-    OPCHK(hipMemcpy(dmaps, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
-    OPCHK(hipMemcpy(dmaps + rm.size(), cm.data(), cm.size() * 4, hipMemcpyHostToDevice));
-    ConvArgs a;
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dw), hw.size() * 4));
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dmaps), (rm.size() + cm.size()) * 4));
+    OPCHK(hipMemcpy(oc.dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(oc.dmaps, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(oc.dmaps + rm.size(), cm.data(), cm.size() * 4, hipMemcpyHostToDevice));
+    ConvArgs& a = oc.a;
     memset(&a, 0, sizeof a);
     a.x = x; a.x_bs = (long)Cin * Hin * Win; a.Cin = Cin; a.Hin = Hin; a.Win = Win;
-    a.w = dw; a.bias = bias_host ? dw + wcount : nullptr; a.ss = ss; a.act_in = act_in; a.act_out = act_out;
-    if (wb_floats) a.wb = dw + wcount + pk.Cout_pad;
-    a.rowmap = dmaps; a.colmap = dmaps + rm.size();
+    a.w = oc.dw; a.bias = bias_host ? oc.dw + wcount : nullptr; a.ss = ss; a.act_in = act_in; a.act_out = act_out;
+    if (wb_floats) a.wb = oc.dw + wcount + pk.Cout_pad;
+    a.rowmap = oc.dmaps; a.colmap = oc.dmaps + rm.size();
     a.vec4 = (ksize == 1 && ((Hin * Win) % 4 == 0)) ? 1 : 0;
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
@@ -1439,10 +1447,105 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
     a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
+    oc.variant = g.variant;
+    return LNS_OK;
+}
+
+int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv, const float* w_host,
+                  const float* bias_host, int Cout, int ksize, int stride, int dilation, int pad_t, int pad_b, int pad_l,
+                  int pad_r, int mode_y, int mode_x, const float* ss, int act_in, int act_out, const float* residual,
+                  const float* badd, float* y, int tile_variant, void* stream) {
+    OpConv oc;
+    const int rc = op_conv_prepare(oc, x, B, Cin, Hin, Win, Hv, Wv, w_host, bias_host, Cout, ksize, stride, dilation, pad_t,
+                                   pad_b, pad_l, pad_r, mode_y, mode_x, ss, act_in, act_out, residual, badd, y, tile_variant);
+    if (rc) { oc.release(); return rc; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    OPCHK(launch_conv(g.variant, a, s));
+    OPCHK(launch_conv(oc.variant, oc.a, s));
     OPCHK(hipStreamSynchronize(s));
-    (void)hipFree(dw); (void)hipFree(dmaps);
+    oc.release();
+    return LNS_OK;
+}
+
+// Diagnostic: two convolutions launched repeatedly on two streams (so their workgroups share CUs), each
+// compared bit for bit with the result it gives alone.  A: ksize_a x ksize_a, B: ksize_b x ksize_b, both on
+// [B, C, H, W] inputs with a GroupNorm+Swish prologue; variants as in lns_op_conv2d (-1 = automatic fp32).
+int lns_op_conv_pair_stress(int B, int H, int W, int cin_a, int cout_a, int ksize_a, int variant_a, int cin_b, int cout_b,
+                            int ksize_b, int variant_b, int rounds, int launches, long long* mismatches_a,
+                            long long* mismatches_b) {
+    struct Side { OpConv oc; float *x = nullptr, *y = nullptr, *ss = nullptr; std::vector<float> ref, out, hx, hw, hs; size_t ny = 0; };
+    bool dumped = false;
+    Side S[2];
+    const int cin[2] = {cin_a, cin_b}, cout[2] = {cout_a, cout_b}, ks[2] = {ksize_a, ksize_b}, var[2] = {variant_a, variant_b};
+    uint64_t seed = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return (float)((seed >> 40) & 0xFFFF) / 32768.0f - 1.0f; };
+    hipStream_t st[2];
+    for (int i = 0; i < 2; ++i) OPCHK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        Side& s = S[i];
+        const size_t nx = (size_t)B * cin[i] * H * W;
+        s.ny = (size_t)B * cout[i] * H * W;
+        std::vector<float>&hx = s.hx, &hw = s.hw, &hs = s.hs;
+        hx.resize(nx); hw.resize((size_t)cout[i] * cin[i] * ks[i] * ks[i]); hs.resize((size_t)B * cin[i] * 2);
+        for (auto& v : hx) v = rnd();
+        for (auto& v : hw) v = rnd() / sqrtf((float)cin[i] * ks[i] * ks[i]);
+        for (size_t k = 0; k < hs.size(); ++k) hs[k] = (k & 1) ? 0.1f * rnd() : 1.0f + 0.1f * rnd();
+        OPCHK(hipMalloc(reinterpret_cast<void**>(&s.x), nx * 4));
+        OPCHK(hipMalloc(reinterpret_cast<void**>(&s.y), s.ny * 4));
+        OPCHK(hipMalloc(reinterpret_cast<void**>(&s.ss), hs.size() * 4));
+        OPCHK(hipMemcpy(s.x, hx.data(), nx * 4, hipMemcpyHostToDevice));
+        OPCHK(hipMemcpy(s.ss, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+        const int p = ks[i] / 2;
+        const int rc = op_conv_prepare(s.oc, s.x, B, cin[i], H, W, H, W, hw.data(), nullptr, cout[i], ks[i], 1, 1, p, p, p, p,
+                                       1, 1, s.ss, ACT_SWISH, ACT_NONE, nullptr, nullptr, s.y, var[i]);
+        if (rc) return rc;
+        s.ref.resize(s.ny); s.out.resize(s.ny);
+        OPCHK(launch_conv(s.oc.variant, s.oc.a, st[i]));
+        OPCHK(hipStreamSynchronize(st[i]));
+        OPCHK(hipMemcpy(s.ref.data(), s.y, s.ny * 4, hipMemcpyDeviceToHost));
+    }
+    long long bad[2] = {0, 0};
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = 0; i < 2; ++i) OPCHK(hipMemsetAsync(S[i].y, 0xFF, S[i].ny * 4, st[i]));
+        for (int l = 0; l < launches; ++l)
+            for (int i = 0; i < 2; ++i) OPCHK(launch_conv(S[i].oc.variant, S[i].oc.a, st[i]));
+        for (int i = 0; i < 2; ++i) {
+            OPCHK(hipStreamSynchronize(st[i]));
+            OPCHK(hipMemcpy(S[i].out.data(), S[i].y, S[i].ny * 4, hipMemcpyDeviceToHost));
+            long long nb = 0;
+            for (size_t k = 0; k < S[i].ny; ++k)
+                if (memcmp(&S[i].out[k], &S[i].ref[k], 4) != 0) {
+                    if (nb < 6 && getenv("LNS_STRESS_VERBOSE")) {
+                        const size_t hw = (size_t)H * W, per = (size_t)cout[i] * hw;
+                        fprintf(stderr, "  side %c round %d: sample %zu channel %zu pixel %zu  got %.9g  want %.9g\n", 'A' + i, r,
+                                k / per, (k % per) / hw, k % hw, S[i].out[k], S[i].ref[k]);
+                    }
+                    ++nb;
+                }
+            if (nb && getenv("LNS_STRESS_VERBOSE")) fprintf(stderr, "  side %c round %d: %lld words differ\n", 'A' + i, r, nb);
+            if (nb && getenv("LNS_STRESS_DUMP") && !dumped) {
+                dumped = true;
+                const std::string d = getenv("LNS_STRESS_DUMP");
+                auto put = [&](const char* nm, const void* p, size_t bytes) {
+                    FILE* f = fopen((d + "/" + nm).c_str(), "wb");
+                    if (f) { fwrite(p, 1, bytes, f); fclose(f); }
+                };
+                put("out.bin", S[i].out.data(), S[i].ny * 4);
+                put("ref.bin", S[i].ref.data(), S[i].ny * 4);
+                put("x.bin", S[i].hx.data(), S[i].hx.size() * 4);
+                put("w.bin", S[i].hw.data(), S[i].hw.size() * 4);
+                put("ss.bin", S[i].hs.data(), S[i].hs.size() * 4);
+                fprintf(stderr, "  dumped side %c (B=%d C=%d->%d k=%d HW=%dx%d)\n", 'A' + i, B, cin[i], cout[i], ks[i], H, W);
+            }
+            bad[i] += nb;
+        }
+    }
+    for (int i = 0; i < 2; ++i) {
+        S[i].oc.release();
+        (void)hipFree(S[i].x); (void)hipFree(S[i].y); (void)hipFree(S[i].ss);
+        (void)hipStreamDestroy(st[i]);
+    }
+    if (mismatches_a) *mismatches_a = bad[0];
+    if (mismatches_b) *mismatches_b = bad[1];
     return LNS_OK;
 }
 

@@ -40,7 +40,7 @@ struct ConvArgs {
     // before the residual add.  w2: packed [Cout][Cout2_pad] slab of the 1x1 weight, bias2 [Cout].
     const float* w2; const float* bias2; int Cout2_pad;
     // bf16x3 path (3x3, stride 1): weights pre-split into 3 bf16 terms,
-    // layout [cout tile][stage of 8 ch][split 3][tap pair 5][k half 2][64 cout][8 ch]
+    // layout [cout tile][stage of 8 ch][split 3][tap 9][64 cout][8 ch]
     const void* wb;
     int B;
 };
@@ -56,7 +56,7 @@ bool conv_fits(int variant, const ConvArgs& a);
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 // 3x3 convolution on bf16 MFMA with every fp32 operand split into three bf16 terms (6 products,
 // two accumulators): fp32-level accuracy at 2.7x the fp32-MFMA rate.  Tile 64 couts x 128 pixels.
-#define CONVB_SLAB_BYTES 30720           // one (cout tile, stage) weight slab
+#define CONVB_SLAB_BYTES 27648           // one (cout tile, stage) weight slab: 3 splits x 9 taps x 64 couts x 8 ch bf16
 size_t convb_lds_bytes(const ConvArgs& a);
 bool convb_fits(const ConvArgs& a);
 hipError_t launch_conv_bf16x3(const ConvArgs& a, hipStream_t s);

@@ -533,14 +533,15 @@ hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
 //           every layer mix (15.5k vs 16.4k trajectory-steps/s) and is not instantiated -- see DESIGN.md.
 //   stage : 8 input channels; MFMA K=16 = 2 taps x 8 channels (9 taps padded to 10)
 //   LDS   : patch  [split][pixel][8 ch] bf16 (16-byte units: conflict-free b128 reads),
-//           weights [split][tap pair][k half][cout][8 ch] bf16 (straight copy of the host slab)
+//           weights [split][tap 0..8][cout][8 ch] bf16 (straight copy of the host slab); the 10th,
+//           non-existent tap of the last k-step reads a shared all-zero patch unit instead
 //   same software pipeline as the fp32 kernel (register prefetch two stages ahead, staging
 //   interleaved with the MFMA steps, one barrier per stage); prologue transform, padding maps,
 //   epilogue (bias / act / fused 1x1 / residual) identical.
 // ===========================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define CONVB_MAXU 3      // patch units (pixel x 8 channels) per thread per stage
-#define CONVB_NWU 8       // weight 16-byte units per thread per stage (1920 per slab)
+#define CONVB_MAXU 2      // patch units (pixel x 8 channels) per thread per stage
+#define CONVB_NWU 7       // weight 16-byte units per thread per stage (1728 per slab)
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -556,17 +557,18 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned& h, unsig
     l = pk_bf16(rx - __uint_as_float(m << 16), ry - __uint_as_float(m & 0xffff0000u));
 }
 
-template <int NT, bool FUSE2>
+template <int NT, int NU, bool FUSE2>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     constexpr int NTHR = 256, TM = 64, TN = 128 * NT, MT = 2, KC = 8, NJ = 5;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int PH = a.PH, PW = a.PW;
     const int PLANE = PH * PW;
-    const int PPAD = (PLANE + 3) & ~3;
-    const int xb_bytes = 3 * PPAD * 16;
+    const int PP1 = PLANE + 1;                         // plane stride in units; unit PLANE = write sink
+    const int xb_bytes = 3 * PP1 * 16;
     const int buf_bytes = xb_bytes + CONVB_SLAB_BYTES;
     char* lds = smem;                                                  // 2 x [Xb | Wb]
-    float* ssl = reinterpret_cast<float*>(lds + 2 * buf_bytes);        // [Cin_pad][2]
+    char* zunit = lds + 2 * buf_bytes;                                 // one all-zero 16-byte unit
+    float* ssl = reinterpret_cast<float*>(zunit + 16);                 // [Cin_pad][2]
     int* rmap = reinterpret_cast<int*>(ssl + a.Cin_pad * 2);
     int* cmap = rmap + PH;
 
@@ -587,13 +589,15 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
     for (int i = tid; i < PH; i += NTHR) rmap[i] = a.rowmap[ty * BH * a.stride + i];
     for (int i = tid; i < PW; i += NTHR) cmap[i] = a.colmap[tx * BW * a.stride + i];
+    if (tid < 4) reinterpret_cast<unsigned*>(zunit)[tid] = 0u;
     __syncthreads();
 
-    // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or -1
-    int udesc[CONVB_MAXU];
-    const int nunit = (PLANE + NTHR - 1) / NTHR;
+    // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or -1.
+    // Threads past the end of the patch stage into the sink unit, so the K loop has no branches.
+    int udm[NU], uslot[NU];
+    float uok[NU];
 #pragma unroll
-    for (int u = 0; u < CONVB_MAXU; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int p = tid + u * NTHR;
         int d = -1;
         if (p < PLANE) {
@@ -601,22 +605,30 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             const int sy = rmap[py], sx = cmap[px];
             if (sy >= 0 && sx >= 0) d = sy * a.Win + sx;
         }
-        udesc[u] = d;
+        udm[u] = d >= 0 ? d : 0;
+        uok[u] = d >= 0 ? 1.0f : 0.0f;
+        uslot[u] = (p < PLANE ? p : PLANE) * 16;
     }
     // weight slab of this cout tile: CONVB_SLAB_BYTES per stage, copied 16 bytes per thread-slot
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)ct * (a.Cin_pad / KC) * CONVB_SLAB_BYTES;
 
-    int boff[NT], ltoff[NJ];
+    // per-lane operand offsets (bytes).  K of one MFMA = 2 taps x 8 channels: lane half kh takes tap 2j+kh.
+    // The 10th tap does not exist: in k-step 4 the kh=1 lanes multiply the shared zero unit with tap 8's
+    // (finite) weights.
+    int boff[NT], ltoff[NJ], aoff[NJ];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
-        boff[nt] = ((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride;
+        boff[nt] = (((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride) * 16;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int t = 2 * j + kh;                       // this lane half's tap in k-step j (tap 9 = zero pad)
-        ltoff[j] = t < 9 ? ((t / 3) * a.dil) * PW + (t % 3) * a.dil : 0;
+        const int t = 2 * j + kh;
+        const int tc = t < 9 ? t : 8;
+        ltoff[j] = (((tc / 3) * a.dil) * PW + (tc % 3) * a.dil) * 16;
+        aoff[j] = (tc * TM + l31) * 16;
     }
+    const bool ztap = kh != 0;                          // k-step 4: this lane half reads the zero unit
 
     f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
 #pragma unroll
@@ -626,51 +638,51 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc_hi[mt][nt][r] = 0.0f; acc_lo[mt][nt][r] = 0.0f; }
 
-    float pv[CONVB_MAXU][KC];
+    float pv[NU][KC];                 // raw prefetched patch values (stage + 2 while in flight)
+    unsigned hq[NU][4], mq[NU][4], lq[NU][4];   // split + packed channel pairs of the stage being written
     float wq[CONVB_NWU][4];
 
-    auto load_unit = [&](int u, int c0) __attribute__((always_inline)) {
-        const int d = udesc[u];
+    // channel pair cp (channels 2cp, 2cp+1 of a stage) of unit u: global -> registers.
+    // Straight-line code (no per-element branches, so the scheduler can interleave it with MFMAs):
+    // a padded pixel reads pixel 0 and is multiplied by 0 later; a channel past Cin reads channel 0
+    // (finite data) and meets zero weights.
+    auto load_pair = [&](int u, int cp, int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const bool ok = d >= 0 && (c0 + c) < a.Cin;
-            const float* src = ok ? xb + ((long)(c0 + c) * HWin + d) : xb;
-            pv[u][c] = *src;
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + 2 * cp + e;
+            const float* cb = xb + (long)(c < a.Cin ? c : 0) * HWin;     // uniform
+            pv[u][2 * cp + e] = cb[udm[u]];
         }
+    };
+    // prologue transform + 3-way split of one channel pair
+    auto split_pair = [&](auto mode_tag, int u, int cp, int c0) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        float t[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = pv[u][2 * cp + e];
+            if (MODE >= 1) { const float2 st = *reinterpret_cast<const float2*>(ssl + 2 * (c0 + 2 * cp + e)); v = v * st.x + st.y; }
+            if (MODE == 2) v = swish_fast(v);
+            t[e] = v * uok[u];
+        }
+        split3_pair(t[0], t[1], hq[u][cp], mq[u][cp], lq[u][cp]);
+    };
+    auto flush_unit = [&](int u, char* Xn) __attribute__((always_inline)) {
+        char* dst = Xn + uslot[u];
+        *reinterpret_cast<uint4*>(dst) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
+        *reinterpret_cast<uint4*>(dst + PP1 * 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
+        *reinterpret_cast<uint4*>(dst + 2 * PP1 * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
     };
     auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
         const int idx = tid + i * NTHR;                  // 16-byte unit inside the slab
-        const int off = idx < CONVB_SLAB_BYTES / 16 ? idx : 0;
+        const int off = idx < CONVB_SLAB_BYTES / 16 ? idx : CONVB_SLAB_BYTES / 16 - 1;
         const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB_SLAB_BYTES + (long)off * 16);
         wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
     };
-    auto write_unit = [&](auto mode_tag, int u, int c0, char* Xn) __attribute__((always_inline)) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        const int p = tid + u * NTHR;
-        const int d = udesc[u];
-        uint4 vh, vm, vl;
-        float t[KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            float v = pv[u][c];
-            if (MODE >= 1) { const float2 st = *reinterpret_cast<const float2*>(ssl + 2 * (c0 + c)); v = v * st.x + st.y; }
-            if (MODE == 2) v = swish_fast(v);
-            t[c] = (d >= 0 && (c0 + c) < a.Cin) ? v : 0.0f;
-        }
-        split3_pair(t[0], t[1], vh.x, vm.x, vl.x);
-        split3_pair(t[2], t[3], vh.y, vm.y, vl.y);
-        split3_pair(t[4], t[5], vh.z, vm.z, vl.z);
-        split3_pair(t[6], t[7], vh.w, vm.w, vl.w);
-        if (p < PPAD) {
-            *reinterpret_cast<uint4*>(Xn + ((long)(0 * PPAD + p)) * 16) = vh;
-            *reinterpret_cast<uint4*>(Xn + ((long)(1 * PPAD + p)) * 16) = vm;
-            *reinterpret_cast<uint4*>(Xn + ((long)(2 * PPAD + p)) * 16) = vl;
-        }
-    };
     auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
-        const int idx = tid + i * NTHR;
-        if (idx < CONVB_SLAB_BYTES / 16)
-            *reinterpret_cast<float4*>(Wn + (long)idx * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
+        const int idx = tid + i * NTHR;                  // the last slot's tail rewrites the slab's last unit
+        const int off = idx < CONVB_SLAB_BYTES / 16 ? idx : CONVB_SLAB_BYTES / 16 - 1;
+        *reinterpret_cast<float4*>(Wn + (long)off * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
     };
 
     // fragments of k-step j: A[s][mt] (couts), B[s][nt] (pixels), s = h / m / l
@@ -680,28 +692,43 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         for (int s = 0; s < 3; ++s) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                af[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + ((((s * NJ + j) * 2 + kh) * TM) + mt * 32 + l31) * 16);
+                af[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + s * (9 * TM * 16) + mt * (32 * 16) + aoff[j]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                bf[s][nt] = *reinterpret_cast<const bf16x8*>(Xs + ((long)(s * PPAD + boff[nt] + ltoff[j])) * 16);
+            for (int nt = 0; nt < NT; ++nt) {
+                const char* p = Xs + s * PP1 * 16 + boff[nt] + ltoff[j];
+                if (j == NJ - 1) p = ztap ? zunit : p;
+                bf[s][nt] = *reinterpret_cast<const bf16x8*>(p);
+            }
         }
     };
 
+    // One K loop per prologue mode.  Stage = 8 channels; per k-step 6*MT*NT MFMAs.  The staging of
+    // stage c+1 (registers -> LDS, with the transform and split) and the prefetch of stage c+2
+    // (global -> registers) are cut into per-k-step pieces (one channel pair per unit, two weight
+    // slots) and interleaved with the MFMAs by scheduling groups, so the matrix pipe keeps running
+    // while a wave stages; one barrier per stage.
     auto k_loop = [&](auto mode_tag) __attribute__((always_inline)) {
         const int last = a.Cin_pad - KC;
-        constexpr int NSLOT = CONVB_MAXU + CONVB_NWU;
 #pragma unroll
-        for (int u = 0; u < CONVB_MAXU; ++u) if (u < nunit) load_unit(u, 0);
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) load_pair(u, cp, 0);
 #pragma unroll
         for (int i = 0; i < CONVB_NWU; ++i) load_w(i, 0);
 #pragma unroll
-        for (int u = 0; u < CONVB_MAXU; ++u) if (u < nunit) write_unit(mode_tag, u, 0, lds);
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) split_pair(mode_tag, u, cp, 0);
+            flush_unit(u, lds);
+        }
 #pragma unroll
         for (int i = 0; i < CONVB_NWU; ++i) write_w(i, lds + xb_bytes);
         {
             const int c1 = KC < last ? KC : last;
 #pragma unroll
-            for (int u = 0; u < CONVB_MAXU; ++u) if (u < nunit) load_unit(u, c1);
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) load_pair(u, cp, c1);
 #pragma unroll
             for (int i = 0; i < CONVB_NWU; ++i) load_w(i, c1);
         }
@@ -719,30 +746,38 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (j + 1 < NJ) load_frags(j + 1, Xs, Ws, af[(j + 1) & 1], bf[(j + 1) & 1]);
+                auto& A = af[j & 1];
+                auto& Bq = bf[j & 1];
+                // product-major order: consecutive MFMAs belong to different accumulators
+#define LNS_BX3(ACC, SA, SB)                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
+            ACC[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA][mt], Bq[SB][nt], ACC[mt][nt], 0, 0, 0);
+                LNS_BX3(acc_lo, 1, 1)
+                LNS_BX3(acc_hi, 0, 0)
+                LNS_BX3(acc_lo, 0, 2)
+                LNS_BX3(acc_lo, 2, 0)
+                LNS_BX3(acc_lo, 0, 1)
+                LNS_BX3(acc_lo, 1, 0)
+#undef LNS_BX3
+                if (j < 4) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int u = 0; u < NU; ++u) { split_pair(mode_tag, u, j, cw); load_pair(u, j, cl2); }
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        auto& A = af[j & 1];
-                        auto& Bq = bf[j & 1];
-                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bq[1][nt], acc_lo[mt][nt], 0, 0, 0);
-                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bq[2][nt], acc_lo[mt][nt], 0, 0, 0);
-                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], Bq[0][nt], acc_lo[mt][nt], 0, 0, 0);
-                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bq[1][nt], acc_lo[mt][nt], 0, 0, 0);
-                        acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bq[0][nt], acc_lo[mt][nt], 0, 0, 0);
-                        acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bq[0][nt], acc_hi[mt][nt], 0, 0, 0);
-                    }
-                // staging slots spread over the k-steps: 11 slots over 5 steps
+                    for (int i = 2 * j; i < 2 * j + 2; ++i)
+                        if (i < CONVB_NWU) { write_w(i, Wn); load_w(i, cl2); }
+                } else {
 #pragma unroll
-                for (int qq = 0; qq < 3; ++qq) {
-                    const int q = j * 3 + qq;
-                    if (q >= NSLOT) continue;
-                    if (q < CONVB_MAXU) {
-                        if (q < nunit) { write_unit(mode_tag, q, cw, Xn); load_unit(q, cl2); }
-                    } else {
-                        write_w(q - CONVB_MAXU, Wn);
-                        load_w(q - CONVB_MAXU, cl2);
-                    }
+                    for (int u = 0; u < NU; ++u) flush_unit(u, Xn);
+                }
+                // interleave: after each MFMA a few of the step's other instructions
+#pragma unroll
+                for (int g = 0; g < 6 * MT * NT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -851,8 +886,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 }
 
 size_t convb_lds_bytes(const ConvArgs& a) {
-    const size_t ppad = ((size_t)a.PH * a.PW + 3) & ~(size_t)3;
-    return 2 * (3 * ppad * 16 + CONVB_SLAB_BYTES) + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
+    const size_t pp1 = (size_t)a.PH * a.PW + 1;
+    return 2 * (3 * pp1 * 16 + CONVB_SLAB_BYTES) + 16 + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
 }
 
 bool convb_fits(const ConvArgs& a) {
@@ -887,9 +922,8 @@ void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, in
                 q[0] = host_bf16_rne(v, &hb);
                 q[1] = host_bf16_rne(v - hb, &mb);
                 q[2] = host_bf16_rne((v - hb) - mb, &lb);
-                const int j = t / 2, kh = t % 2;
                 for (int sidx = 0; sidx < 3; ++sidx) {
-                    const size_t unit = ((((size_t)ct * nstage + st) * 3 + sidx) * 5 + j) * 2 + kh;
+                    const size_t unit = (((size_t)ct * nstage + st) * 3 + sidx) * 9 + t;
                     d[(unit * 64 + cl) * 8 + c] = q[sidx];
                 }
             }
@@ -901,8 +935,14 @@ hipError_t launch_conv_bf16x3(const ConvArgs& a, hipStream_t s) {
     if (!convb_fits(a)) return hipErrorInvalidValue;
     dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
     const size_t lds = convb_lds_bytes(a);
-    if (a.w2) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, false>), grid, dim3(256), lds, s, a);
+    const bool two = (long)a.PH * a.PW > 256;            // patch units per thread
+    if (a.w2) {
+        if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true>), grid, dim3(256), lds, s, a);
+    } else {
+        if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false>), grid, dim3(256), lds, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -1832,8 +1872,10 @@ hipError_t init_kernels() {
     LNS_SET_LDS((fa_sandwich_kernel<2, 3, false>))
     LNS_SET_LDS((fa_sandwich_kernel<2, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<2, 1, false>))
-    LNS_SET_LDS((conv3_bf16x3_kernel<1, true>))
-    LNS_SET_LDS((conv3_bf16x3_kernel<1, false>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false>))
     LNS_SET_LDS(fa_lrk_kernel)
     LNS_SET_LDS(fa_pool_kernel)
     LNS_SET_LDS(fa_reducer_kernel)

@@ -15,6 +15,7 @@ cases = {
     "inproj": dict(B=64, Cin=64, Cout=512, H=64, W=64, k=1, ss=True, act=0),
 }
 which = sys.argv[1:] or list(cases)
+VARIANT = int(os.environ.get("CONV_VARIANT", "-1"))   # 6 = bf16x3 kernel
 for name in which:
     c = cases[name]
     B, Cin, Cout, H, W, k = c["B"], c["Cin"], c["Cout"], c["H"], c["W"], c["k"]
@@ -27,7 +28,7 @@ for name in which:
     y = torch.empty(B, Cout, Hv, Wv, device="cuda")
     for it in range(3):
         rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, Hv, Wv, gc._hp(w), gc._hp(bias), Cout, k, 1, 1, p, p, p, p, 1, 1,
-                             ss.data_ptr(), c["act"], 0, None, None, y.data_ptr(), -1, None)
+                             ss.data_ptr(), c["act"], 0, None, None, y.data_ptr(), VARIANT if k == 3 else -1, None)
         assert rc == 0
     torch.cuda.synchronize()
     print(name, "done")

@@ -100,7 +100,7 @@ struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Ho
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
                           int kc_log2_pack, int Cout_pad, int force_variant, bool need_wgm1 = false,
-                          bool allow_bf16x3 = false) {
+                          bool allow_bf16x3 = false, int Cin = 1 << 30) {
     g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
     g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
     if (g.Hout <= 0 || g.Wout <= 0) return false;
@@ -118,16 +118,21 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
     if (force_variant < 0 && use_b) {   // fp32 variants only if the geometry rules the bf16x3 tiles out
         cands.insert(cands.begin(), (int)CV_B64);
     }
+    static const bool no_b1 = getenv("LNS_CONV1_FP32_MFMA") != nullptr;
+    // 1x1: bf16x3 unless the layer is a thin projection (few output channels / a handful of input channels:
+    // bandwidth-bound, and a 64-cout MFMA tile would be mostly padding) -- again a per-layer rule
+    if (force_variant < 0 && allow_bf16x3 && !no_bf16x3 && !no_b1 && k == 1 && stride == 1 && Cout > 32 && Cin >= 16)
+        cands = {(int)CV_B1};
     g.kc_log2 = conv_pick_kc_log2(k, stride, kc_log2_pack);
     static const int pref[] = {5, 6, 4, 7, 3, 8};   // log2 BW preference on ties: 32,64,16,128,8,256
     bool found = false;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         const ConvVariantInfo vi = conv_variant_info(cands[ci]);
-        if (Cout_pad % vi.TM != 0) continue;
+        if (cands[ci] < CV_B64 && Cout_pad % vi.TM != 0) continue;   // fp32 pack layout
         ConvArgs tmp;
         memset(&tmp, 0, sizeof tmp);
         tmp.ks = k; tmp.kc_log2 = g.kc_log2; tmp.Cin_pad = 1 << kc_log2_pack;
-        if (cands[ci] == CV_B64) { tmp.stride = stride; tmp.Cin_pad = 512; tmp.wb = &tmp; }
+        if (cands[ci] >= CV_B64) { tmp.stride = stride; tmp.Cin_pad = 512; tmp.wb = &tmp; }
         int best_bw = -1, txn = 0, tyn = 0, best_kc = g.kc_log2;
         if (k == 1) {
             // 1x1: the image is a flat array of H*W pixels, a tile is TN consecutive pixels
@@ -167,7 +172,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         g.PH = tmp.PH; g.PW = tmp.PW; g.sel_kc_log2 = best_kc;
         found = true;
         static const long min_blocks = getenv("LNS_CONV_MIN_BLOCKS") ? atol(getenv("LNS_CONV_MIN_BLOCKS")) : 128;
-        if (cands[ci] == CV_B64) break;                        // never fall through to fp32 by launch size
+        if (cands[ci] >= CV_B64) break;                        // never fall through to fp32 by launch size
         if (blocks >= min_blocks) break;
     }
     return found;
@@ -314,7 +319,7 @@ struct Planner {
         if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
         const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
         ConvGeom g;
-        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb))
+        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb, pk.cin))
             throw std::runtime_error("no conv tiling for " + name);
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
@@ -337,7 +342,14 @@ struct Planner {
         memset(&a, 0, sizeof a);
         a.x = as_ptr<const float>(in.ptr); a.x_bs = in.bs; a.Cin = in.C; a.Hin = in.H; a.Win = in.W;
         a.w = as_ptr<const float>(wt(pk.w_off));
-        if (g.variant == CV_B64) a.wb = as_ptr<const void>(wt(pk.wb_off));
+        if (g.variant >= CV_B64) a.wb = as_ptr<const void>(wt(pk.wb_off));
+        if (g.variant == CV_B1 && pk.Cin_pad <= 64 && g.cout_tiles >= 2 && fuse_pack < 0) {
+            // input-stationary form; the number of cout tiles per block only changes the launch shape, never a bit
+            static const bool off = getenv("LNS_CONV1_NO_STATIONARY") != nullptr;
+            int cpb = g.cout_tiles;
+            while (cpb > 2 && (long)B * g.tiles_x * ((g.cout_tiles + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
+            if (!off) a.ct_per_block = cpb;
+        }
         a.bias = pk.has_bias ? as_ptr<const float>(wt(pk.b_off)) : nullptr;
         a.ss = as_ptr<const float>(in.ss);
         a.act_in = in.act; a.act_out = act_out;
@@ -745,8 +757,11 @@ static int finalize_weights(lns_engine* e, int device) {
     for (ConvPack& p : e->packs) {
         p.w_off = off; off += round_up_sz((size_t)p.k * p.k * p.Cin_pad * p.Cout_pad, 64);
         p.b_off = off; off += round_up_sz((size_t)p.Cout_pad, 64);
-        p.has_wb = p.k == 3 && p.Cin_pad % 8 == 0 && p.cout > 32;
-        if (p.has_wb) { p.wb_off = off; off += round_up_sz(convb_weight_bytes(p.cout, p.Cin_pad) / 4, 64); }
+        p.has_wb = (p.k == 3 && p.Cin_pad % 8 == 0 && p.cout > 32) || (p.k == 1 && p.Cin_pad % 32 == 0);
+        if (p.has_wb) {
+            p.wb_off = off;
+            off += round_up_sz((p.k == 3 ? convb_weight_bytes(p.cout, p.Cin_pad) : convb1_weight_bytes(p.cout, p.Cin_pad)) / 4, 64);
+        }
     }
     for (VecPack& v : e->vecs) { v.off = off; off += round_up_sz(v.count, 64); }
     std::vector<float> host(off, 0.0f);
@@ -755,7 +770,8 @@ static int finalize_weights(lns_engine* e, int device) {
         for (size_t i = 0; i < p.wkeys.size(); ++i) {
             const Param& w = e->params[e->pindex.at(p.wkeys[i])];
             pack_conv_weight(host.data() + p.w_off, w.host.data(), co, p.couts[i], p.cin, p.k, p.Cin_pad, p.Cout_pad);
-            if (p.has_wb) convb_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
+            if (p.has_wb && p.k == 3) convb_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
+            if (p.has_wb && p.k == 1) convb1_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
             if (!p.bkeys[i].empty()) {
                 const Param& b = e->params[e->pindex.at(p.bkeys[i])];
                 memcpy(host.data() + p.b_off + co, b.host.data(), (size_t)p.couts[i] * 4);
@@ -1399,6 +1415,8 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     if (!x || !w_host || !y || (ksize != 1 && ksize != 3)) return LNS_EINVAL;
     if (act_in != ACT_NONE && act_in != ACT_SWISH) return LNS_EINVAL;   // prologue: GroupNorm scale/shift + Swish only
     OPCHK(init_kernels());
+    const bool stationary = tile_variant == 8;      // test code: 1x1 bf16x3 kernel in its input-stationary form
+    if (stationary) tile_variant = CV_B1;
     ConvPack pk;
     pk.cin = Cin; pk.cout = Cout; pk.k = ksize;
     pk.kc_log2 = ksize == 3 ? 3 : 5;
@@ -1424,10 +1442,12 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     std::vector<float> hw(wcount + pk.Cout_pad, 0.0f);
     pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
     if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
-    const size_t wb_floats = g.variant == CV_B64 ? convb_weight_bytes(Cout, pk.Cin_pad) / 4 : 0;
+    const size_t wb_floats = g.variant == CV_B64 ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
+                           : g.variant == CV_B1 ? convb1_weight_bytes(Cout, pk.Cin_pad) / 4 : 0;
     if (wb_floats) {
         hw.resize(hw.size() + wb_floats, 0.0f);
-        convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
+        if (g.variant == CV_B64) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
+        else convb1_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
     }
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dw), hw.size() * 4));
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dmaps), (rm.size() + cm.size()) * 4));
@@ -1447,6 +1467,10 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
     a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
+    if (stationary) {
+        if (pk.Cin_pad > 64) return LNS_EINVAL;
+        a.ct_per_block = g.cout_tiles < 3 ? g.cout_tiles : 3;
+    }
     oc.variant = g.variant;
     return LNS_OK;
 }

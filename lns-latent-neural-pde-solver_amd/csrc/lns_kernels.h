@@ -42,12 +42,13 @@ struct ConvArgs {
     // bf16x3 path (3x3, stride 1): weights pre-split into 3 bf16 terms,
     // layout [cout tile][stage of 8 ch][split 3][tap 9][64 cout][8 ch]
     const void* wb;
+    int ct_per_block;      // 1x1 bf16x3, input-stationary form: cout tiles walked by one block (0 = streaming form)
     int B;
 };
 
 // tile variants: (TM couts x TN pixels) per 256-thread block
 enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4, CV_S32 = 5, CV_COUNT = 6,
-                   CV_B64 = 6 /* bf16x3 3x3 kernel, 64 couts x 128 pixels */ };
+                   CV_B64 = 6 /* bf16x3 3x3 kernel */, CV_B1 = 7 /* bf16x3 1x1 kernel */ };   // both 64 couts x 128 pixels
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
 size_t conv_lds_bytes(int variant, const ConvArgs& a);
@@ -63,6 +64,12 @@ hipError_t launch_conv_bf16x3(const ConvArgs& a, hipStream_t s);
 // host-side packing of one [Cout][Cin][3][3] weight (cout offset co0 inside the pack) into the bf16x3 slab layout
 size_t convb_weight_bytes(int Cout, int Cin_pad);
 void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);
+// 1x1 bf16x3 kernel: slabs [cout tile][stage of 32 ch][split 3][octet 4][64 cout][8 ch], Cin_pad % 32 == 0
+size_t convb1_lds_bytes(const ConvArgs& a);
+bool convb1_fits(const ConvArgs& a);
+size_t convb1_weight_bytes(int Cout, int Cin_pad);
+void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);
+hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // GroupNorm statistics -> per-(b,c) scale/shift (fused into the consumer conv)

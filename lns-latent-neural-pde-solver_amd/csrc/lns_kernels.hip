@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 static const ConvVariantInfo kConvInfo[CV_COUNT] = {
     {128, 256}, {64, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 128}};
 
-ConvVariantInfo conv_variant_info(int v) { return v == CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v]; }
+ConvVariantInfo conv_variant_info(int v) { return v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v]; }
 
 // Stage depth (channels per LDS stage).  It is a function of the kernel size ONLY
 // (3x3: 4, 1x1: 16), never of the tile variant or batch: the fp32
@@ -465,6 +465,7 @@ static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8
 
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
     if (variant == CV_B64) return convb_lds_bytes(a);
+    if (variant == CV_B1) return convb1_lds_bytes(a);
     const int KC = 1 << a.kc_log2;
     const int TM = kConvInfo[variant].TM;
     const size_t xs = (size_t)conv_maxe(a.ks, KC) * 256;
@@ -474,6 +475,7 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 
 bool conv_fits(int variant, const ConvArgs& a) {
     if (variant == CV_B64) return convb_fits(a);
+    if (variant == CV_B1) return convb1_fits(a);
     const long KC = 1 << a.kc_log2;
     const int TN = kConvInfo[variant].TN;
     if (a.ks == 3 ? (KC != 4 && KC != 8) : (KC != 16)) return false;
@@ -506,6 +508,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
     if (variant == CV_B64) return launch_conv_bf16x3(a, s);
+    if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
     if (!conv_fits(variant, a)) return hipErrorInvalidValue;
     const size_t lds = conv_lds_bytes(variant, a);
     switch (variant) {
@@ -555,6 +558,106 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned& h, unsig
     const float rx = x - __uint_as_float(h << 16), ry = y - __uint_as_float(h & 0xffff0000u);
     m = pk_bf16(rx, ry);
     l = pk_bf16(rx - __uint_as_float(m << 16), ry - __uint_as_float(m & 0xffff0000u));
+}
+
+// Shared epilogue of the bf16x3 kernels (64-cout tile, wave = 64 couts x 32*NT pixels): sums the two
+// accumulators, then bias / per-sample add / activation / fused second 1x1 conv (fp32 MFMA, the
+// accumulator tile as B operand, see conv_mfma_kernel) / residual, and the coalesced stores.
+// pix[nt]: flat output pixel of this lane in pixel tile nt, or -1.
+template <int NT, bool FUSE2>
+__device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[2][NT], f32x16 (&acc_lo)[2][NT],
+                                               const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds) {
+    constexpr int MT = 2, TM = 64, NTHR = 256;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc_hi[mt][nt][r] + acc_lo[mt][nt][r];
+    const int HWo = a.Hout * a.Wout;
+    float* yb = a.y + (long)b * a.y_bs;
+    const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+    if (a.bias || a.badd) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int cob = ct * TM + mt * 32 + 4 * kh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                const int cc = co < a.Cout ? co : 0;
+                float add = 0.0f;
+                if (a.bias) add += a.bias[cc];
+                if (a.badd) add += a.badd[(long)b * a.Cout + cc];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
+            }
+        }
+    }
+    if (a.act_out == ACT_GELU) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_apply(acc[mt][nt][r], ACT_GELU);
+    } else if (a.act_out == ACT_SWISH) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
+    }
+    if (FUSE2) {
+        float* W2s = reinterpret_cast<float*>(lds);
+        __syncthreads();
+        for (int i = tid; i < TM * TM / 4; i += NTHR) {
+            const int k = i / (TM / 4), c4 = i - k * (TM / 4);
+            *reinterpret_cast<float4*>(W2s + k * TM + c4 * 4) =
+                *reinterpret_cast<const float4*>(a.w2 + (long)k * a.Cout2_pad + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc2[MT];
+#pragma unroll
+            for (int m2 = 0; m2 < MT; ++m2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[m2][r] = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            W2s[(mt * 32 + drow(r, kh)) * TM + m2 * 32 + l31], acc[mt][nt][r], acc2[m2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < MT; ++m2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[m2][nt][r] = acc2[m2][r] + (a.bias2 ? a.bias2[m2 * 32 + drow(r, kh)] : 0.0f);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (pix[nt] < 0) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int cob = ct * TM + mt * 32 + 4 * kh;
+            float* yp = yb + ((long)cob * HWo + pix[nt]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                if (co < a.Cout) {
+                    const int ro = ((r & 3) + 8 * (r >> 2)) * HWo;
+                    float v = acc[mt][nt][r];
+                    if (rb) v += rb[(long)cob * HWo + pix[nt] + ro];
+                    yp[ro] = v;
+                }
+            }
+        }
+    }
 }
 
 template <int NT, int NU, bool FUSE2>
@@ -790,99 +893,422 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     else k_loop(std::integral_constant<int, 0>{});
 
     // ---- epilogue (fp32) ---------------------------------------------------------
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc_hi[mt][nt][r] + acc_lo[mt][nt][r];
-    const int HWo = a.Hout * a.Wout;
-    float* yb = a.y + (long)b * a.y_bs;
-    const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
-    if (a.bias || a.badd) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int cob = ct * TM + mt * 32 + 4 * kh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cob + (r & 3) + 8 * (r >> 2);
-                const int cc = co < a.Cout ? co : 0;
-                float add = 0.0f;
-                if (a.bias) add += a.bias[cc];
-                if (a.badd) add += a.badd[(long)b * a.Cout + cc];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
-            }
-        }
-    }
-    if (a.act_out == ACT_GELU) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_apply(acc[mt][nt][r], ACT_GELU);
-    } else if (a.act_out == ACT_SWISH) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
-    }
-    if (FUSE2) {   // second 1x1 conv in fp32 (see conv_mfma_kernel): the accumulator tile is the B operand
-        float* W2s = reinterpret_cast<float*>(lds);
-        __syncthreads();
-        for (int i = tid; i < TM * TM / 4; i += NTHR) {
-            const int k = i / (TM / 4), c4 = i - k * (TM / 4);
-            *reinterpret_cast<float4*>(W2s + k * TM + c4 * 4) =
-                *reinterpret_cast<const float4*>(a.w2 + (long)k * a.Cout2_pad + c4 * 4);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x16 acc2[MT];
-#pragma unroll
-            for (int m2 = 0; m2 < MT; ++m2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[m2][r] = 0.0f;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            W2s[(mt * 32 + drow(r, kh)) * TM + m2 * 32 + l31], acc[mt][nt][r], acc2[m2], 0, 0, 0);
-            }
-#pragma unroll
-            for (int m2 = 0; m2 < MT; ++m2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[m2][nt][r] = acc2[m2][r] + (a.bias2 ? a.bias2[m2 * 32 + drow(r, kh)] : 0.0f);
-        }
-    }
+    int pix[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
         const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
-        if (!((oy < a.Hout) && (ox < a.Wout))) continue;
-        const int pix = oy * a.Wout + ox;
+        pix[nt] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : -1;
+    }
+    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds);
+}
+
+// ===========================================================================
+// 1x1 convolution on the bf16 matrix pipe (same split scheme as the 3x3 kernel above).
+//   tile  : 64 couts x 128 consecutive pixels of one sample, 4 waves (wave = 64 couts x 32 pixels)
+//   stage : 32 input channels = 2 MFMA k-steps (K = 16 channels: lane half kh takes one 8-channel octet)
+//   LDS   : pixels  [split][octet 0..3][pixel 0..127][8 ch] bf16, weights [split][octet][cout][8 ch] bf16
+//   staging unit = (pixel, octet): 8 channel values of one pixel, two units per thread per stage
+// A 1x1 conv has no tap reuse, so the fp32 -> 3 x bf16 split (VALU) is about as much work as the MFMAs;
+// it is interleaved with them the same way as in the 3x3 kernel.
+// ===========================================================================
+#define CONVB1_SLAB_BYTES 12288          // 3 splits x 4 octets x 64 couts x 8 ch bf16
+template <bool VEC2, bool FUSE2>
+__global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
+    constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, NWU = 3;
+    constexpr int XB = 3 * 4 * TN * 16;                               // 24576
+    constexpr int BUF = XB + CONVB1_SLAB_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds = smem;                                                  // 2 x [Xb | Wb]
+    float* ssl = reinterpret_cast<float*>(lds + 2 * BUF);              // [Cin_pad][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.y;
+    int bid = blockIdx.x;
+    const int ct = bid % a.cout_tiles;
+    const int tx = bid / a.cout_tiles;
+    const int HW = a.Hin * a.Win;
+    const int p0 = tx * TN;
+    const float* xb = a.x + (long)b * a.x_bs;
+    const bool has_ss = a.ss != nullptr;
+    const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
+
+    for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
+        ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+    __syncthreads();
+
+    // two staging units (pixel, octet) per thread.  VEC2 (even H*W): two adjacent pixels of one octet, fetched
+    // with 8-byte loads; otherwise one pixel, octets o and o + 2.
+    int upx[NU], uoct[NU], udm[NU];
+    float uok[NU];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int cob = ct * TM + mt * 32 + 4 * kh;
-            float* yp = yb + ((long)cob * HWo + pix);
+    for (int u = 0; u < NU; ++u) {
+        upx[u] = VEC2 ? 2 * (tid & 63) + u : (tid & 127);
+        uoct[u] = VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u;
+        const bool pvalid = p0 + upx[u] < HW;
+        udm[u] = pvalid ? p0 + upx[u] : 0;
+        uok[u] = pvalid ? 1.0f : 0.0f;
+    }
+    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)ct * (a.Cin_pad / KC) * CONVB1_SLAB_BYTES;
+    const int aoff = (kh * TM + l31) * 16;                 // + (s*4 + 2j) * TM*16 + mt*32*16
+    const int boff = (kh * TN + wn * 32 + l31) * 16;       // + (s*4 + 2j) * TN*16
+
+    f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cob + (r & 3) + 8 * (r >> 2);
-                if (co < a.Cout) {
-                    const int ro = ((r & 3) + 8 * (r >> 2)) * HWo;
-                    float v = acc[mt][nt][r];
-                    if (rb) v += rb[(long)cob * HWo + pix + ro];
-                    yp[ro] = v;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_hi[mt][0][r] = 0.0f; acc_lo[mt][0][r] = 0.0f; }
+
+    float pv[NU][8];
+    unsigned hq[NU][4], mq[NU][4], lq[NU][4];
+    float wq[NWU][4];
+
+    // channel pair cp of both units: global -> registers
+    auto load_pairs = [&](int cp, int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (VEC2) {
+                const int c = c0 + uoct[0] * 8 + 2 * cp + e;           // uniform per wave
+                const float* cb = xb + (long)(c < a.Cin ? c : 0) * HW;
+                const float2 t = *reinterpret_cast<const float2*>(cb + udm[0]);
+                pv[0][2 * cp + e] = t.x; pv[1][2 * cp + e] = t.y;
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = c0 + uoct[u] * 8 + 2 * cp + e;
+                    const float* cb = xb + (long)(c < a.Cin ? c : 0) * HW;
+                    pv[u][2 * cp + e] = cb[udm[u]];
                 }
             }
         }
+    };
+    auto split_pair = [&](auto mode_tag, int u, int cp, int c0) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        float t[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = pv[u][2 * cp + e];
+            if (MODE >= 1) {
+                const float2 st = *reinterpret_cast<const float2*>(ssl + 2 * (c0 + uoct[u] * 8 + 2 * cp + e));
+                v = v * st.x + st.y;
+            }
+            if (MODE == 2) v = swish_fast(v);
+            t[e] = v * uok[u];
+        }
+        split3_pair(t[0], t[1], hq[u][cp], mq[u][cp], lq[u][cp]);
+    };
+    auto flush_unit = [&](int u, char* Xn) __attribute__((always_inline)) {
+        char* dst = Xn + (uoct[u] * TN + upx[u]) * 16;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
+        *reinterpret_cast<uint4*>(dst + 4 * TN * 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
+        *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
+    };
+    auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
+        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB1_SLAB_BYTES + (long)(tid + i * NTHR) * 16);
+        wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
+    };
+    auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
+        *reinterpret_cast<float4*>(Wn + (long)(tid + i * NTHR) * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
+    };
+    auto load_frags = [&](int j, const char* Xs, const char* Ws, bf16x8 (&af)[3][MT], bf16x8 (&bf)[3])
+                          __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                af[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + (s * 4 + 2 * j) * (TM * 16) + mt * (32 * 16) + aoff);
+            bf[s] = *reinterpret_cast<const bf16x8*>(Xs + (s * 4 + 2 * j) * (TN * 16) + boff);
+        }
+    };
+
+    auto k_loop = [&](auto mode_tag) __attribute__((always_inline)) {
+        const int last = a.Cin_pad - KC;
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) load_pairs(cp, 0);
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) load_w(i, 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) split_pair(mode_tag, u, cp, 0);
+            flush_unit(u, lds);
+        }
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) write_w(i, lds + XB);
+        {
+            const int c1 = KC < last ? KC : last;
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) load_pairs(cp, c1);
+#pragma unroll
+            for (int i = 0; i < NWU; ++i) load_w(i, c1);
+        }
+        __syncthreads();
+        int buf = 0;
+        for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
+            const char* Xs = lds + buf * BUF;
+            const char* Ws = Xs + XB;
+            char* Xn = lds + (buf ^ 1) * BUF;
+            char* Wn = Xn + XB;
+            const int cw = c0 + KC < last ? c0 + KC : last;
+            const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
+            bf16x8 af[2][3][MT], bf[2][3];
+            load_frags(0, Xs, Ws, af[0], bf[0]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 1 < NJ) load_frags(j + 1, Xs, Ws, af[(j + 1) & 1], bf[(j + 1) & 1]);
+                auto& A = af[j & 1];
+                auto& Bq = bf[j & 1];
+#define LNS_BX1(ACC, SA, SB)                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
+        ACC[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA][mt], Bq[SB], ACC[mt][0], 0, 0, 0);
+                LNS_BX1(acc_lo, 1, 1)
+                LNS_BX1(acc_hi, 0, 0)
+                LNS_BX1(acc_lo, 0, 2)
+                LNS_BX1(acc_lo, 2, 0)
+                LNS_BX1(acc_lo, 0, 1)
+                LNS_BX1(acc_lo, 1, 0)
+#undef LNS_BX1
+                // k-step j stages channel pairs 2j, 2j+1 of both units and half of the weight slots
+#pragma unroll
+                for (int cp = 2 * j; cp < 2 * j + 2; ++cp) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) split_pair(mode_tag, u, cp, cw);
+                    load_pairs(cp, cl2);
+                }
+                if (j == NJ - 1) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) flush_unit(u, Xn);
+                }
+#pragma unroll
+                for (int i = 2 * j; i < 2 * j + 2; ++i)
+                    if (i < NWU) { write_w(i, Wn); load_w(i, cl2); }
+#pragma unroll
+                for (int g = 0; g < 6 * MT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    };
+    if (pro_mode == 2) k_loop(std::integral_constant<int, 2>{});
+    else if (pro_mode == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
+
+    int pix[NT];
+    {
+        const int p = p0 + wn * 32 + l31;
+        pix[0] = p < a.Hout * a.Wout ? p : -1;
     }
+    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds);
+}
+
+// Input-stationary form of the 1x1 kernel for narrow inputs (Cin_pad <= 64) feeding many output channels:
+// the pixel tile is transformed, split and staged ONCE (it fits the two stage buffers), then the block walks
+// over `a.ct_per_block` cout tiles streaming only weight slabs.  Same accumulation order per output as the
+// streaming form (stage 0 then stage 1, k-steps in order), so either form gives the same bits.
+template <bool VEC2>
+__global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
+    constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, NWU = 3;
+    constexpr int XB = 3 * 4 * TN * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xres = smem;                                                 // [stage 0..1][Xb]
+    char* wbuf = smem + 2 * XB;                                        // [2][slab]
+    float* ssl = reinterpret_cast<float*>(wbuf + 2 * CONVB1_SLAB_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.y;
+    const int nchunk = (a.cout_tiles + a.ct_per_block - 1) / a.ct_per_block;
+    const int chunk = blockIdx.x % nchunk, tx = blockIdx.x / nchunk;
+    const int ct0 = chunk * a.ct_per_block;
+    const int nct = min(a.ct_per_block, a.cout_tiles - ct0);
+    const int nstage = a.Cin_pad / KC;                                 // 1 or 2
+    const int HW = a.Hin * a.Win;
+    const int p0 = tx * TN;
+    const float* xb = a.x + (long)b * a.x_bs;
+    const bool has_ss = a.ss != nullptr;
+
+    for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
+        ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+    __syncthreads();
+
+    // ---- stage the whole pixel tile (all channels) ----------------------------------
+    {
+        int upx[NU], uoct[NU], udm[NU];
+        float uok[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            upx[u] = VEC2 ? 2 * (tid & 63) + u : (tid & 127);
+            uoct[u] = VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u;
+            const bool pvalid = p0 + upx[u] < HW;
+            udm[u] = pvalid ? p0 + upx[u] : 0;
+            uok[u] = pvalid ? 1.0f : 0.0f;
+        }
+        for (int st = 0; st < nstage; ++st) {
+            float pv[NU][8];
+#pragma unroll
+            for (int ce = 0; ce < 8; ++ce) {
+                if (VEC2) {
+                    const int c = st * KC + uoct[0] * 8 + ce;
+                    const float2 t = *reinterpret_cast<const float2*>(xb + (long)(c < a.Cin ? c : 0) * HW + udm[0]);
+                    pv[0][ce] = t.x; pv[1][ce] = t.y;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int c = st * KC + uoct[u] * 8 + ce;
+                        pv[u][ce] = xb[(long)(c < a.Cin ? c : 0) * HW + udm[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                unsigned hq[4], mq[4], lq[4];
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) {
+                    float t[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float v = pv[u][2 * cp + e];
+                        if (has_ss) {
+                            const float2 sv = *reinterpret_cast<const float2*>(ssl + 2 * (st * KC + uoct[u] * 8 + 2 * cp + e));
+                            v = v * sv.x + sv.y;
+                            if (a.act_in == ACT_SWISH) v = swish_fast(v);
+                        }
+                        t[e] = v * uok[u];
+                    }
+                    split3_pair(t[0], t[1], hq[cp], mq[cp], lq[cp]);
+                }
+                char* dst = xres + st * XB + (uoct[u] * TN + upx[u]) * 16;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+                *reinterpret_cast<uint4*>(dst + 4 * TN * 16) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
+                *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+            }
+        }
+    }
+
+    // ---- walk over (cout tile, stage) pairs, streaming weight slabs ---------------------
+    const int aoff = (kh * TM + l31) * 16;
+    const int boff = (kh * TN + wn * 32 + l31) * 16;
+    const int nit = nct * nstage;
+    const char* wslab0 = reinterpret_cast<const char*>(a.wb) + (long)ct0 * nstage * CONVB1_SLAB_BYTES;   // slabs are (ct, stage)-major
+    float wq[NWU][4];
+    auto load_w = [&](int i, int it) __attribute__((always_inline)) {
+        const int itc = it < nit ? it : nit - 1;
+        const float4 t = *reinterpret_cast<const float4*>(wslab0 + (long)itc * CONVB1_SLAB_BYTES + (long)(tid + i * NTHR) * 16);
+        wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
+    };
+    auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
+        *reinterpret_cast<float4*>(Wn + (long)(tid + i * NTHR) * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
+    };
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) load_w(i, 0);
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) write_w(i, wbuf);
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) load_w(i, 1);
+    __syncthreads();
+
+    f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
+    int pix[NT];
+    {
+        const int p = p0 + wn * 32 + l31;
+        pix[0] = p < a.Hout * a.Wout ? p : -1;
+    }
+    int st = 0, ctl = 0;
+    for (int it = 0; it < nit; ++it) {
+        if (st == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc_hi[mt][0][r] = 0.0f; acc_lo[mt][0][r] = 0.0f; }
+        }
+        const char* Xs = xres + st * XB;
+        const char* Ws = wbuf + (it & 1) * CONVB1_SLAB_BYTES;
+        char* Wn = wbuf + ((it + 1) & 1) * CONVB1_SLAB_BYTES;
+        bf16x8 af[2][3][MT], bf[2][3];
+        auto load_frags = [&](int j, bf16x8 (&afj)[3][MT], bf16x8 (&bfj)[3]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    afj[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + (s * 4 + 2 * j) * (TM * 16) + mt * (32 * 16) + aoff);
+                bfj[s] = *reinterpret_cast<const bf16x8*>(Xs + (s * 4 + 2 * j) * (TN * 16) + boff);
+            }
+        };
+        load_frags(0, af[0], bf[0]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j + 1 < NJ) load_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
+            auto& A = af[j & 1];
+            auto& Bq = bf[j & 1];
+#define LNS_BX1(ACC, SA, SB)                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
+        ACC[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA][mt], Bq[SB], ACC[mt][0], 0, 0, 0);
+            LNS_BX1(acc_lo, 1, 1)
+            LNS_BX1(acc_hi, 0, 0)
+            LNS_BX1(acc_lo, 0, 2)
+            LNS_BX1(acc_lo, 2, 0)
+            LNS_BX1(acc_lo, 0, 1)
+            LNS_BX1(acc_lo, 1, 0)
+#undef LNS_BX1
+#pragma unroll
+            for (int i = 2 * j; i < 2 * j + 2; ++i)
+                if (i < NWU) { write_w(i, Wn); load_w(i, it + 2); }
+#pragma unroll
+            for (int g = 0; g < 6 * MT; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (++st == nstage) {
+            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem);
+            st = 0;
+            ++ctl;
+        }
+    }
+}
+
+size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (3 * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 16; }
+
+bool convb1_fits(const ConvArgs& a) {
+    return a.ks == 1 && a.stride == 1 && (a.Cin_pad % 32) == 0 && a.wb != nullptr && convb1_lds_bytes(a) <= 150 * 1024;
+}
+
+size_t convb1_weight_bytes(int Cout, int Cin_pad) { return (size_t)((Cout + 63) / 64) * (Cin_pad / 32) * CONVB1_SLAB_BYTES; }
+
+hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s) {
+    if (!convb1_fits(a)) return hipErrorInvalidValue;
+    dim3 grid(a.tiles_x * a.cout_tiles, a.B);
+    const size_t lds = convb1_lds_bytes(a);
+    const bool vec2 = ((a.Hin * a.Win) % 2 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && (a.x_bs % 2 == 0);
+    if (a.ct_per_block > 0) {     // input-stationary form (planner: Cin_pad <= 64, several cout tiles, no fused conv)
+        if (a.w2 || a.Cin_pad > 64) return hipErrorInvalidValue;
+        const int nchunk = (a.cout_tiles + a.ct_per_block - 1) / a.ct_per_block;
+        dim3 gs(a.tiles_x * nchunk, a.B);
+        if (vec2) hipLaunchKernelGGL((conv1s_bf16x3_kernel<true>), gs, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv1s_bf16x3_kernel<false>), gs, dim3(256), lds, s, a);
+        return hipGetLastError();
+    }
+    if (a.w2) {
+        if (vec2) hipLaunchKernelGGL((conv1_bf16x3_kernel<true, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv1_bf16x3_kernel<false, true>), grid, dim3(256), lds, s, a);
+    } else {
+        if (vec2) hipLaunchKernelGGL((conv1_bf16x3_kernel<true, false>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv1_bf16x3_kernel<false, false>), grid, dim3(256), lds, s, a);
+    }
+    return hipGetLastError();
 }
 
 size_t convb_lds_bytes(const ConvArgs& a) {
@@ -926,6 +1352,27 @@ void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, in
                     const size_t unit = (((size_t)ct * nstage + st) * 3 + sidx) * 9 + t;
                     d[(unit * 64 + cl) * 8 + c] = q[sidx];
                 }
+            }
+        }
+    }
+}
+
+void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad) {
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    const int nstage = Cin_pad / 32;
+    for (int co = 0; co < cout; ++co) {
+        const int cog = co0 + co, ct = cog / 64, cl = cog % 64;
+        for (int ci = 0; ci < cin; ++ci) {
+            const int st = ci / 32, oct = (ci % 32) / 8, c = ci % 8;
+            const float v = w[(size_t)co * cin + ci];
+            float hb, mb, lb;
+            uint16_t q[3];
+            q[0] = host_bf16_rne(v, &hb);
+            q[1] = host_bf16_rne(v - hb, &mb);
+            q[2] = host_bf16_rne((v - hb) - mb, &lb);
+            for (int sidx = 0; sidx < 3; ++sidx) {
+                const size_t unit = (((size_t)ct * nstage + st) * 3 + sidx) * 4 + oct;
+                d[(unit * 64 + cl) * 8 + c] = q[sidx];
             }
         }
     }
@@ -1872,6 +2319,12 @@ hipError_t init_kernels() {
     LNS_SET_LDS((fa_sandwich_kernel<2, 3, false>))
     LNS_SET_LDS((fa_sandwich_kernel<2, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<2, 1, false>))
+    LNS_SET_LDS((conv1s_bf16x3_kernel<true>))
+    LNS_SET_LDS((conv1s_bf16x3_kernel<false>))
+    LNS_SET_LDS((conv1_bf16x3_kernel<true, true>))
+    LNS_SET_LDS((conv1_bf16x3_kernel<true, false>))
+    LNS_SET_LDS((conv1_bf16x3_kernel<false, true>))
+    LNS_SET_LDS((conv1_bf16x3_kernel<false, false>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true>))

@@ -120,6 +120,20 @@ for _c in [dict(B=2, Cin=64, Cout=64, H=32, W=32, mode=(1, 1)), dict(B=2, Cin=64
            dict(B=2, Cin=128, Cout=128, H=16, W=16, ss=True, act_in=1, act_out=2, badd=True),
            dict(B=2, Cin=40, Cout=72, H=20, W=36, mode=(0, 0)), dict(B=1, Cin=512, Cout=64, H=32, W=32, mode=(1, 1), ss=True)]:
     CONV_CASES.append(dict(k=3, variant=6, **_c))
+# bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel
+# counts, prologue and epilogue features
+for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, Cout=128, H=16, W=16),
+           dict(B=2, Cin=128, Cout=16, H=16, W=16, ss=True, act_in=1), dict(B=2, Cin=64, Cout=3, H=64, W=64, ss=True, act_in=1),
+           dict(B=2, Cin=64, Cout=512, H=32, W=32, ss=True, bias=False), dict(B=2, Cin=512, Cout=64, H=32, W=32, act_out=2, bias=False),
+           dict(B=2, Cin=64, Cout=64, H=61, W=121, ss=True, act_in=1, res=True), dict(B=2, Cin=128, Cout=64, H=30, W=60, bias=False),
+           dict(B=3, Cin=64, Cout=2048, H=1, W=64, bias=False), dict(B=2, Cin=40, Cout=72, H=7, W=15, ss=True, badd=True),
+           dict(B=1, Cin=96, Cout=96, H=20, W=36, ss=True, act_in=1, act_out=2)]:
+    CONV_CASES.append(dict(k=1, variant=7, **_c))
+# the same kernel in its input-stationary form (variant code 8: blocks walk over 3 cout tiles, ragged last chunk)
+for _c in [dict(B=2, Cin=64, Cout=512, H=32, W=32, ss=True, bias=False), dict(B=2, Cin=16, Cout=128, H=16, W=16),
+           dict(B=2, Cin=40, Cout=200, H=7, W=15, ss=True, act_in=1, act_out=2, badd=True),
+           dict(B=3, Cin=64, Cout=2048, H=1, W=64, bias=False), dict(B=1, Cin=64, Cout=448, H=61, W=121, ss=True, act_in=1, res=True)]:
+    CONV_CASES.append(dict(k=1, variant=8, **_c))
 for _v in range(6):   # every tile variant on the same problem
     CONV_CASES.append(dict(B=2, Cin=64, Cout=(32 if _v == 5 else 128 if _v in (0, 2) else 64), H=32, W=32, k=3,
                            mode=(1, 1), variant=_v))

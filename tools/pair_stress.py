@@ -36,3 +36,6 @@ if __name__ == "__main__":
     run("bf16x3 3x3 64->64  | fp32 1x1 64->512", 32, 64, 64, (64, 64, 3, 6), (64, 512, 1, -1), rounds=12)
     run("fp32 3x3 64->64    | fp32 1x1 64->64", 32, 64, 64, (64, 64, 3, 1), (64, 64, 1, -1), rounds=12)
     run("fp32 1x1 64->64    | fp32 1x1 64->64", 32, 64, 64, (64, 64, 1, -1), (64, 64, 1, -1), rounds=12)
+    run("bf16x3 3x3 64->64  | bf16x3 1x1 64->64", 32, 64, 64, (64, 64, 3, 6), (64, 64, 1, 7), rounds=12)
+    run("bf16x3 1x1 64->512 | bf16x3 1x1 512->64", 16, 64, 64, (64, 512, 1, 7), (512, 64, 1, 7), rounds=12)
+    run("bf16x3 1x1 64->64  | fp32 1x1 64->64", 32, 64, 64, (64, 64, 1, 7), (64, 64, 1, 1), rounds=12)

@@ -1607,17 +1607,30 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.0f;
 
     const int ntile = (n + 31) / 32;
+    // K/V tile kt+1 is fetched into registers while tile kt is being used
+    constexpr int NKV = D * 32 / 256;
+    float kpre[NKV], vpre[NKV];
+    auto fetch = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NKV; ++u) {
+            const int i = tid + u * 256, d = i >> 5, key = kt * 32 + (i & 31);
+            const bool kv = key < n;
+            kpre[u] = kv ? kb[(long)d * n + key] : 0.0f;
+            vpre[u] = kv ? vb[(long)d * n + key] : 0.0f;
+        }
+    };
+    fetch(0);
     for (int kt = 0; kt < ntile; ++kt) {
         const int key0 = kt * 32;
         __syncthreads();
-        for (int i = tid; i < D * 32; i += 256) {
-            const int d = i >> 5, j = i & 31;
-            const int key = key0 + j;
-            const bool kv = key < n;
-            Ks[d * 32 + j] = kv ? kb[(long)d * n + key] : 0.0f;
-            Vs[d * 33 + j] = kv ? vb[(long)d * n + key] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < NKV; ++u) {
+            const int i = tid + u * 256, d = i >> 5, j = i & 31;
+            Ks[d * 32 + j] = kpre[u];
+            Vs[d * 33 + j] = vpre[u];
         }
         __syncthreads();
+        if (kt + 1 < ntile) fetch(kt + 1);
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
@@ -1768,7 +1781,128 @@ __global__ __launch_bounds__(256) void fa_reducer_kernel(FaReducerArgs a) {
     }
 }
 
+// MFMA form (C and Hid multiples of 32): 32 pooled rows per block are the 32 "pixels" (MFMA columns) of three
+// chained small GEMMs whose activations never leave LDS ([channel][row], so an accumulator tile is written
+// back with one row per lane and read again as the next B operand); weights (in-major = [k][m]) are staged
+// through one LDS region per GEMM, the last one in chunks of 128 outputs.
+#define FARM_R 32
+#define FARM_RP 33
+__global__ __launch_bounds__(256) void fa_reducer_mfma_kernel(FaReducerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = a.C, Hid = a.Hid, Out = a.Out;
+    const int wt_floats = max(C * Hid, Hid * 128);
+    float* Wt = reinterpret_cast<float*>(smem);           // current weight matrix / chunk, [k][m]
+    float* X0 = Wt + wt_floats;                           // [C][RP]   pooled rows
+    float* X1 = X0 + C * FARM_RP;                         // [C][RP]   to_in output / LayerNorm
+    float* X2 = X1 + C * FARM_RP;                         // [Hid][RP] hidden
+    float* red = X2 + Hid * FARM_RP;                      // [8][32] LayerNorm partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const long row0 = (long)blockIdx.x * FARM_R;
+
+    // global -> LDS staging with 16 loads in flight per thread (a plain copy loop keeps one)
+    auto stage = [&](float* dst, int n, auto src) __attribute__((always_inline)) {
+        for (int base = 0; base < n; base += 256 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = base + tid + u * 256; v[u] = i < n ? src(i) : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = base + tid + u * 256; if (i < n) dst[i] = v[u]; }
+        }
+    };
+    stage(Wt, C * C, [&](int i) { return a.win_t[i]; });
+    for (int base = 0; base < FARM_R * C; base += 256 * 8) {     // m[row][c] -> X0[c][r]
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + tid + u * 256, r = i / C, c = i - r * C;
+            v[u] = (i < FARM_R * C && row0 + r < a.rows) ? a.m[(row0 + r) * C + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + tid + u * 256, r = i / C, c = i - r * C;
+            if (i < FARM_R * C) X0[c * FARM_RP + r] = v[u];
+        }
+    }
+    __syncthreads();
+    // out[m][r] = sum_k W[k][m] * X[k][r] for the 32-row tile mt of W's columns
+    auto gemm_tile = [&](const float* W, int ldw, int m0, const float* X, int K) __attribute__((always_inline)) -> f32x16 {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float* wp = W + kh * ldw + m0 + l31;
+        const float* xp = X + kh * FARM_RP + l31;
+#pragma unroll 8
+        for (int kk = 0; kk < K / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[2 * kk * ldw], xp[2 * kk * FARM_RP], acc, 0, 0, 0);
+        return acc;
+    };
+    for (int mt = wave; mt < C / 32; mt += 4) {           // to_in
+        const f32x16 acc = gemm_tile(Wt, C, mt * 32, X0, C);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X1[(mt * 32 + drow(r, kh)) * FARM_RP + l31] = acc[r];
+    }
+    __syncthreads();
+    stage(Wt, C * Hid, [&](int i) { return a.w1_t[i]; });           // overlaps with the LayerNorm below
+    {   // LayerNorm over channels, eps 1e-5 (two-pass): 8 partial sums per row
+        const int r = tid & 31, part = tid >> 5, per = C / 8;
+        float sacc = 0.0f;
+        for (int i = part * per; i < (part + 1) * per; ++i) sacc += X1[i * FARM_RP + r];
+        red[part * 32 + r] = sacc;
+        __syncthreads();
+        float mean = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) mean += red[p * 32 + r];
+        mean /= (float)C;
+        __syncthreads();
+        float q = 0.0f;
+        for (int i = part * per; i < (part + 1) * per; ++i) { const float d = X1[i * FARM_RP + r] - mean; q += d * d; }
+        red[part * 32 + r] = q;
+        __syncthreads();
+        float var = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) var += red[p * 32 + r];
+        const float rstd = 1.0f / sqrtf(var / (float)C + 1e-5f);
+        for (int i = part * per; i < (part + 1) * per; ++i)
+            X1[i * FARM_RP + r] = (X1[i * FARM_RP + r] - mean) * rstd * a.ln_g[i] + a.ln_b[i];
+    }
+    __syncthreads();
+    for (int mt = wave; mt < Hid / 32; mt += 4) {         // Linear(C, Hid) + GELU
+        const f32x16 acc = gemm_tile(Wt, Hid, mt * 32, X1, C);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X2[(mt * 32 + drow(r, kh)) * FARM_RP + l31] = act_apply(acc[r], ACT_GELU);
+    }
+    const long row = row0 + l31;
+    const long bi = row / a.n, ii = row - bi * a.n;
+    for (int o0 = 0; o0 < Out; o0 += 128) {                // Linear(Hid, Out) + bias, 128 outputs at a time
+        __syncthreads();
+        const int oc = min(128, Out - o0);
+        stage(Wt, Hid * 128, [&](int i) {
+            const int k = i >> 7, o = i & 127;
+            return o < oc ? a.w2_t[(long)k * Out + o0 + o] : 0.0f;
+        });
+        __syncthreads();
+        for (int mt = wave; mt * 32 < oc; mt += 4) {
+            const f32x16 acc = gemm_tile(Wt, 128, mt * 32, X2, Hid);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + mt * 32 + drow(r, kh);
+                if (o < Out && row < a.rows) a.u[(bi * Out + o) * a.n + ii] = acc[r] + a.b2[o];
+            }
+        }
+    }
+}
+
 hipError_t launch_fa_reducer(const FaReducerArgs& a, hipStream_t s) {
+    static const bool scalar_only = getenv("LNS_FA_REDUCER_SCALAR") != nullptr;   // A/B knob
+    if (!scalar_only && a.C % 32 == 0 && a.Hid % 32 == 0 && a.C <= 256) {
+        const size_t wt = (size_t)std::max(a.C * a.Hid, a.Hid * 128);
+        const size_t lds = (wt + (size_t)(2 * a.C + a.Hid) * FARM_RP + 256) * 4;
+        if (lds <= 160 * 1024) {
+            const unsigned nb = (unsigned)((a.rows + FARM_R - 1) / FARM_R);
+            hipLaunchKernelGGL(fa_reducer_mfma_kernel, dim3(nb), dim3(256), lds, s, a);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = ((size_t)a.C * a.C + (size_t)a.C * a.Hid + (size_t)a.Hid * a.Out +
                         (size_t)FAR_ROWS * (2 * a.C + a.Hid)) * 4;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -1791,20 +1925,28 @@ __global__ __launch_bounds__(256) void fa_lrk_kernel(FaLrkArgs a) {
     const float* qb = a.qk + ((long)b * 2 * a.heads * DK + (long)h * DK) * n;
     const float* kb = qb + (long)a.heads * DK * n;
     const int tid = threadIdx.x;
-    for (int i = tid; i < DK * npad; i += 256) {
-        const int d = i / npad, j = i - d * npad;
-        float qv = 0.0f, kv = 0.0f;
-        if (j < n) {
-            const int dm = d < half ? d : d - half;
-            const float cs = a.cs[((long)j * half + dm) * 2];
-            const float sn = a.cs[((long)j * half + dm) * 2 + 1];
-            const int dp = d < half ? d + half : d - half;
-            const float sg = d < half ? -1.0f : 1.0f;
-            qv = qb[(long)d * n + j] * cs + sg * qb[(long)dp * n + j] * sn;
-            kv = kb[(long)d * n + j] * cs + sg * kb[(long)dp * n + j] * sn;
+    for (int base = 0; base < DK * npad; base += 256 * 8) {      // 8 elements (48 loads) in flight per thread
+        float qv[8], kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + tid + u * 256;
+            const int d = i / npad, j = i - d * npad;
+            qv[u] = 0.0f; kv[u] = 0.0f;
+            if (i < DK * npad && j < n) {
+                const int dm = d < half ? d : d - half;
+                const float cs = a.cs[((long)j * half + dm) * 2];
+                const float sn = a.cs[((long)j * half + dm) * 2 + 1];
+                const int dp = d < half ? d + half : d - half;
+                const float sg = d < half ? -1.0f : 1.0f;
+                qv[u] = qb[(long)d * n + j] * cs + sg * qb[(long)dp * n + j] * sn;
+                kv[u] = kb[(long)d * n + j] * cs + sg * kb[(long)dp * n + j] * sn;
+            }
         }
-        qs[i] = qv;
-        ks[i] = kv;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + tid + u * 256;
+            if (i < DK * npad) { qs[i] = qv[u]; ks[i] = kv[u]; }
+        }
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
@@ -1861,13 +2003,30 @@ __global__ __launch_bounds__(256, (HT * WT >= 6 ? 1 : 2)) void fa_sandwich_kerne
     const int h = blockIdx.y, b = blockIdx.z;
     const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
     const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
-    for (int i = tid; i < HT * 32 * (HT * 32); i += 256) {
-        const int r = i / (HT * 32), c = i - r * (HT * 32);
-        Kxs[r * HP + c] = (r < H && c < H) ? kxg[(long)r * H + c] : 0.0f;
-    }
-    for (int i = tid; i < WT * 32 * (WT * 32); i += 256) {
-        const int r = i / (WT * 32), c = i - r * (WT * 32);
-        Kys[r * WP + c] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
+    // staged with all loads of a thread in flight at once (a plain copy loop keeps one outstanding)
+    {
+        constexpr int NX = HT * 32 * (HT * 32) / 256, NY = WT * 32 * (WT * 32) / 256;
+        float vx[NX], vy[NY];
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256, r = i / (HT * 32), c = i - r * (HT * 32);
+            vx[u] = (r < H && c < H) ? kxg[(long)r * H + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * 256, r = i / (WT * 32), c = i - r * (WT * 32);
+            vy[u] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256, r = i / (HT * 32), c = i - r * (HT * 32);
+            Kxs[r * HP + c] = vx[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * 256, r = i / (WT * 32), c = i - r * (WT * 32);
+            Kys[r * WP + c] = vy[u];
+        }
     }
     float* Ps = Pall + wave * (32 * WP);
     for (int i = lane; i < 32 * WP; i += 64) Ps[i] = 0.0f;   // column padding stays zero for every band
@@ -2329,6 +2488,7 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false>))
+    LNS_SET_LDS(fa_reducer_mfma_kernel)
     LNS_SET_LDS(fa_lrk_kernel)
     LNS_SET_LDS(fa_pool_kernel)
     LNS_SET_LDS(fa_reducer_kernel)

@@ -172,6 +172,13 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         g.PH = tmp.PH; g.PW = tmp.PW; g.sel_kc_log2 = best_kc;
         found = true;
         static const long min_blocks = getenv("LNS_CONV_MIN_BLOCKS") ? atol(getenv("LNS_CONV_MIN_BLOCKS")) : 128;
+        if (cands[ci] == CV_B64 && Cout >= 64 && !need_wgm1) {
+            // 32-cout tiles (same accumulation order, same bits) when 64-cout tiles give fewer blocks than this.
+            // Measured on NS2d-128 (16x16 latent layers, 256 -> 512 blocks): no gain (17.9k vs 18.7k
+            // trajectory-steps/s), so the default is off; kept as a tuning knob and covered by the kernel tests.
+            static const long want = getenv("LNS_CONVB32_BELOW") ? atol(getenv("LNS_CONVB32_BELOW")) : 0;
+            if (blocks < want) { g.variant = CV_B32; g.cout_tiles = (Cout + 31) / 32; }
+        }
         if (cands[ci] >= CV_B64) break;                        // never fall through to fp32 by launch size
         if (blocks >= min_blocks) break;
     }
@@ -342,7 +349,7 @@ struct Planner {
         memset(&a, 0, sizeof a);
         a.x = as_ptr<const float>(in.ptr); a.x_bs = in.bs; a.Cin = in.C; a.Hin = in.H; a.Win = in.W;
         a.w = as_ptr<const float>(wt(pk.w_off));
-        if (g.variant >= CV_B64) a.wb = as_ptr<const void>(wt(pk.wb_off));
+        if (g.variant >= CV_B64) a.wb = as_ptr<const void>(wt(pk.wb_off));   // CV_B32 included
         if (g.variant == CV_B1 && pk.Cin_pad <= 64 && g.cout_tiles >= 2 && fuse_pack < 0) {
             // input-stationary form; the number of cout tiles per block only changes the launch shape, never a bit
             static const bool off = getenv("LNS_CONV1_NO_STATIONARY") != nullptr;
@@ -1442,11 +1449,11 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     std::vector<float> hw(wcount + pk.Cout_pad, 0.0f);
     pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
     if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
-    const size_t wb_floats = g.variant == CV_B64 ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
+    const size_t wb_floats = (g.variant == CV_B64 || g.variant == CV_B32) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
                            : g.variant == CV_B1 ? convb1_weight_bytes(Cout, pk.Cin_pad) / 4 : 0;
     if (wb_floats) {
         hw.resize(hw.size() + wb_floats, 0.0f);
-        if (g.variant == CV_B64) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
+        if (g.variant != CV_B1) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
         else convb1_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
     }
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dw), hw.size() * 4));

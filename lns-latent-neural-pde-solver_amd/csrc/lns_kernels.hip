@@ -448,7 +448,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 static const ConvVariantInfo kConvInfo[CV_COUNT] = {
     {128, 256}, {64, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 128}};
 
-ConvVariantInfo conv_variant_info(int v) { return v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v]; }
+ConvVariantInfo conv_variant_info(int v) {
+    return v == CV_B32 ? ConvVariantInfo{32, 128} : v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v];
+}
 
 // Stage depth (channels per LDS stage).  It is a function of the kernel size ONLY
 // (3x3: 4, 1x1: 16), never of the tile variant or batch: the fp32
@@ -464,7 +466,7 @@ int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
 static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8 : CONV_MAXE3) : CONV_MAXE1; }
 
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
-    if (variant == CV_B64) return convb_lds_bytes(a);
+    if (variant == CV_B64 || variant == CV_B32) return convb_lds_bytes(a, variant == CV_B32 ? 32 : 64);
     if (variant == CV_B1) return convb1_lds_bytes(a);
     const int KC = 1 << a.kc_log2;
     const int TM = kConvInfo[variant].TM;
@@ -474,7 +476,7 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 }
 
 bool conv_fits(int variant, const ConvArgs& a) {
-    if (variant == CV_B64) return convb_fits(a);
+    if (variant == CV_B64 || variant == CV_B32) return convb_fits(a);
     if (variant == CV_B1) return convb1_fits(a);
     const long KC = 1 << a.kc_log2;
     const int TN = kConvInfo[variant].TN;
@@ -507,7 +509,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 }
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
-    if (variant == CV_B64) return launch_conv_bf16x3(a, s);
+    if (variant == CV_B64 || variant == CV_B32) return launch_conv_bf16x3(variant, a, s);
     if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
     if (!conv_fits(variant, a)) return hipErrorInvalidValue;
     const size_t lds = conv_lds_bytes(variant, a);
@@ -564,10 +566,11 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned& h, unsig
 // accumulators, then bias / per-sample add / activation / fused second 1x1 conv (fp32 MFMA, the
 // accumulator tile as B operand, see conv_mfma_kernel) / residual, and the coalesced stores.
 // pix[nt]: flat output pixel of this lane in pixel tile nt, or -1.
-template <int NT, bool FUSE2>
-__device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[2][NT], f32x16 (&acc_lo)[2][NT],
+template <int NT, bool FUSE2, int MT = 2>
+__device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds) {
-    constexpr int MT = 2, TM = 64, NTHR = 256;
+    constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
+    static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -660,15 +663,19 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     }
 }
 
-template <int NT, int NU, bool FUSE2>
+template <int NT, int NU, bool FUSE2, int MT = 2>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
-    constexpr int NTHR = 256, TM = 64, TN = 128 * NT, MT = 2, KC = 8, NJ = 5;
+    // MT = 1: 32-cout tiles (half a weight slab per block).  Same accumulation order, so the planner may pick it
+    // freely; it is used when 64-cout tiles would leave CUs with fewer than two blocks.
+    constexpr int NTHR = 256, TM = 32 * MT, TN = 128 * NT, KC = 8, NJ = 5;
+    constexpr int SLAB = CONVB_SLAB_BYTES * MT / 2;       // bytes of weights per stage in LDS
+    constexpr int NWU = (SLAB / 16 + NTHR - 1) / NTHR;    // weight 16-byte units per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int PH = a.PH, PW = a.PW;
     const int PLANE = PH * PW;
     const int PP1 = PLANE + 1;                         // plane stride in units; unit PLANE = write sink
     const int xb_bytes = 3 * PP1 * 16;
-    const int buf_bytes = xb_bytes + CONVB_SLAB_BYTES;
+    const int buf_bytes = xb_bytes + SLAB;
     char* lds = smem;                                                  // 2 x [Xb | Wb]
     char* zunit = lds + 2 * buf_bytes;                                 // one all-zero 16-byte unit
     float* ssl = reinterpret_cast<float*>(zunit + 16);                 // [Cin_pad][2]
@@ -712,8 +719,10 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         uok[u] = d >= 0 ? 1.0f : 0.0f;
         uslot[u] = (p < PLANE ? p : PLANE) * 16;
     }
-    // weight slab of this cout tile: CONVB_SLAB_BYTES per stage, copied 16 bytes per thread-slot
-    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)ct * (a.Cin_pad / KC) * CONVB_SLAB_BYTES;
+    // weight slab of this cout tile: host slabs hold 64 couts per (split, tap) row; a 32-cout block copies its half
+    // of every row.  16 bytes per thread-slot.
+    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * CONVB_SLAB_BYTES +
+                        (MT == 1 ? (ct & 1) * 512 : 0);
 
     // per-lane operand offsets (bytes).  K of one MFMA = 2 taps x 8 channels: lane half kh takes tap 2j+kh.
     // The 10th tap does not exist: in k-step 4 the kh=1 lanes multiply the shared zero unit with tap 8's
@@ -743,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 
     float pv[NU][KC];                 // raw prefetched patch values (stage + 2 while in flight)
     unsigned hq[NU][4], mq[NU][4], lq[NU][4];   // split + packed channel pairs of the stage being written
-    float wq[CONVB_NWU][4];
+    float wq[NWU][4];
 
     // channel pair cp (channels 2cp, 2cp+1 of a stage) of unit u: global -> registers.
     // Straight-line code (no per-element branches, so the scheduler can interleave it with MFMAs):
@@ -778,13 +787,14 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     };
     auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
         const int idx = tid + i * NTHR;                  // 16-byte unit inside the slab
-        const int off = idx < CONVB_SLAB_BYTES / 16 ? idx : CONVB_SLAB_BYTES / 16 - 1;
-        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB_SLAB_BYTES + (long)off * 16);
+        const int off = idx < SLAB / 16 ? idx : SLAB / 16 - 1;
+        const int src = MT == 1 ? (off >> 5) * 1024 + (off & 31) * 16 : off * 16;     // row of 64 couts -> its 32
+        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB_SLAB_BYTES + src);
         wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
     };
     auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
         const int idx = tid + i * NTHR;                  // the last slot's tail rewrites the slab's last unit
-        const int off = idx < CONVB_SLAB_BYTES / 16 ? idx : CONVB_SLAB_BYTES / 16 - 1;
+        const int off = idx < SLAB / 16 ? idx : SLAB / 16 - 1;
         *reinterpret_cast<float4*>(Wn + (long)off * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
     };
 
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int cp = 0; cp < 4; ++cp) load_pair(u, cp, 0);
 #pragma unroll
-        for (int i = 0; i < CONVB_NWU; ++i) load_w(i, 0);
+        for (int i = 0; i < NWU; ++i) load_w(i, 0);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -825,7 +835,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             flush_unit(u, lds);
         }
 #pragma unroll
-        for (int i = 0; i < CONVB_NWU; ++i) write_w(i, lds + xb_bytes);
+        for (int i = 0; i < NWU; ++i) write_w(i, lds + xb_bytes);
         {
             const int c1 = KC < last ? KC : last;
 #pragma unroll
@@ -833,7 +843,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int cp = 0; cp < 4; ++cp) load_pair(u, cp, c1);
 #pragma unroll
-            for (int i = 0; i < CONVB_NWU; ++i) load_w(i, c1);
+            for (int i = 0; i < NWU; ++i) load_w(i, c1);
         }
         __syncthreads();
         int buf = 0;
@@ -868,7 +878,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                     for (int u = 0; u < NU; ++u) { split_pair(mode_tag, u, j, cw); load_pair(u, j, cl2); }
 #pragma unroll
                     for (int i = 2 * j; i < 2 * j + 2; ++i)
-                        if (i < CONVB_NWU) { write_w(i, Wn); load_w(i, cl2); }
+                        if (i < NWU) { write_w(i, Wn); load_w(i, cl2); }
                 } else {
 #pragma unroll
                     for (int u = 0; u < NU; ++u) flush_unit(u, Xn);
@@ -900,7 +910,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
         pix[nt] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : -1;
     }
-    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds);
+    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds);
 }
 
 // ===========================================================================
@@ -1311,14 +1321,14 @@ hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-size_t convb_lds_bytes(const ConvArgs& a) {
+size_t convb_lds_bytes(const ConvArgs& a, int tm) {
     const size_t pp1 = (size_t)a.PH * a.PW + 1;
-    return 2 * (3 * pp1 * 16 + CONVB_SLAB_BYTES) + 16 + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
+    return 2 * (3 * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
 }
 
 bool convb_fits(const ConvArgs& a) {
     return a.ks == 3 && a.stride == 1 && (a.Cin_pad % 8) == 0 && a.wb != nullptr &&
-           (long)a.PH * a.PW <= CONVB_MAXU * 256 && convb_lds_bytes(a) <= 150 * 1024;
+           (long)a.PH * a.PW <= CONVB_MAXU * 256 && convb_lds_bytes(a, 64) <= 150 * 1024;
 }
 
 size_t convb_weight_bytes(int Cout, int Cin_pad) {
@@ -1378,11 +1388,18 @@ void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, i
     }
 }
 
-hipError_t launch_conv_bf16x3(const ConvArgs& a, hipStream_t s) {
+hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     if (!convb_fits(a)) return hipErrorInvalidValue;
     dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
-    const size_t lds = convb_lds_bytes(a);
     const bool two = (long)a.PH * a.PW > 256;            // patch units per thread
+    if (variant == CV_B32) {                              // 32-cout tiles: a.cout_tiles counts those
+        if (a.w2) return hipErrorInvalidValue;
+        const size_t lds = convb_lds_bytes(a, 32);
+        if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 1>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 1>), grid, dim3(256), lds, s, a);
+        return hipGetLastError();
+    }
+    const size_t lds = convb_lds_bytes(a, 64);
     if (a.w2) {
         if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true>), grid, dim3(256), lds, s, a);
@@ -2484,6 +2501,8 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv1_bf16x3_kernel<true, false>))
     LNS_SET_LDS((conv1_bf16x3_kernel<false, true>))
     LNS_SET_LDS((conv1_bf16x3_kernel<false, false>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 1>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 1>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true>))

@@ -1,0 +1,55 @@
+"""Builds profiles/rNN_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+`python bench.py --serial --steps 1 --warmup 0 --no-cpu-baseline --no-roofline`.
+
+Usage: python tools/make_traffic_json.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import sys
+
+KERNELS = {   # class -> (substring of the kernel name, apply the guide's x2 FETCH_SIZE correction?)
+    "conv3x3": ("conv3_bf16x3_kernel<1, 1, false", False),
+    "conv1x1": ("conv1_bf16x3_kernel<true, false>", False),
+    "conv1x1_stationary": ("conv1s_bf16x3_kernel", False),
+    "fa_sandwich": ("fa_sandwich_kernel<2, 2, true>", True),
+}
+
+
+def per_kernel(path, counter):
+    tot = collections.defaultdict(float)
+    cnt = collections.defaultdict(int)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        tot[r["Kernel_Name"]] += float(r["Counter_Value"])
+        cnt[r["Kernel_Name"]] += 1
+    return tot, cnt
+
+
+def main():
+    f_tot, f_cnt = per_kernel(sys.argv[1], "FETCH_SIZE")
+    w_tot, w_cnt = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python bench.py --serial "
+                   "--steps 1 --warmup 0 --no-cpu-baseline --no-roofline` (MI355X). Counter unit: KB (x1024 = bytes). "
+                   "gfx950 correction: FETCH_SIZE reports half of the bytes of 16-byte-per-lane streaming reads; it is "
+                   "doubled for kernels whose reads are of that kind (fa_sandwich) and left raw for the convolution "
+                   "kernels, whose activation reads are 4 or 8 bytes per lane (uncalibrated).",
+           "kernels": {}}
+    for cls, (sub, x2) in KERNELS.items():
+        names = [n for n in f_tot if sub in n]
+        if not names:
+            continue
+        n = names[0]
+        launches = f_cnt[n]
+        fetch = f_tot[n] * 1024.0 / launches * (2.0 if x2 else 1.0)
+        write = w_tot.get(n, 0.0) * 1024.0 / max(1, w_cnt.get(n, 1))
+        out["kernels"][cls] = {"kernel": n, "launches": launches, "fetch_bytes_per_launch": fetch,
+                               "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+                               "fetch_x2_correction": x2}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -2175,6 +2175,261 @@ __global__ __launch_bounds__(256, (HT * WT >= 6 ? 1 : 2)) void fa_sandwich_kerne
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same sandwich on the bf16 matrix pipe (bf16x3 scheme of the convolution kernels): P, Ky, Kx and the
+// intermediate U are split into three bf16 terms, six products per fp32 product, two accumulators.
+//   LDS: Ky [split][l][m] and Kx [split][i][j'] as bf16 rows (+8 elements of row padding -> 16-byte aligned,
+//        conflict-free b128 fragment reads), a private [split][32 rows][m] band of P per wave.
+//   Kx is stored with its columns permuted inside every 16-block so that the 8 rows of U a lane half holds
+//   in accumulator registers 8t'..8t'+7 (rows (e&3) + 8(e>>2) + 4kh + 16t') are 8 CONSECUTIVE k positions of
+//   the A operand: U is split and packed in registers and is directly the B operand of Y += Kx U.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short bf16_bits(float x) {
+    return __builtin_bit_cast(unsigned short, (__bf16)x);
+}
+__device__ __forceinline__ void split3_scalar(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = bf16_bits(x);
+    const float r1 = x - __uint_as_float((unsigned)h << 16);
+    m = bf16_bits(r1);
+    l = bf16_bits(r1 - __uint_as_float((unsigned)m << 16));
+}
+
+template <int HT, int WT, bool VEC>
+__global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a, int planes_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HB = HT * 32, WB = WT * 32;
+    constexpr int KXW = HB + 8, KYW = WB + 8;               // row strides in bf16 elements
+    constexpr int NPH = 32 * WB / 64;                       // plane floats per lane per 32-row band
+    constexpr int NQH = VEC ? NPH / 4 : NPH;
+    unsigned short* Kxs = reinterpret_cast<unsigned short*>(smem);      // [3][HB][KXW]
+    unsigned short* Kys = Kxs + 3 * HB * KXW;                           // [3][WB][KYW]
+    unsigned short* Pall = Kys + 3 * WB * KYW;                          // 4 x [3][32][KYW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int H = a.H, W = a.W, C = a.C;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
+    const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
+    {   // Kx (column-permuted) and Ky, split, all loads of a thread in flight at once
+        constexpr int NX = HB * HB / 256, NY = WB * WB / 256;
+        float vx[NX], vy[NY];
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256, r = i / HB, c = i - r * HB;
+            vx[u] = (r < H && c < H) ? kxg[(long)r * H + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * 256, r = i / WB, c = i - r * WB;
+            vy[u] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256, r = i / HB, c = i - r * HB;
+            const int w = c & 15;
+            const int cp = (c & ~15) | (w & 3) | (((w >> 3) & 1) << 2) | (((w >> 2) & 1) << 3);
+            unsigned short hh, mm, ll;
+            split3_scalar(vx[u], hh, mm, ll);
+            Kxs[(0 * HB + r) * KXW + cp] = hh; Kxs[(1 * HB + r) * KXW + cp] = mm; Kxs[(2 * HB + r) * KXW + cp] = ll;
+        }
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * 256, r = i / WB, c = i - r * WB;
+            unsigned short hh, mm, ll;
+            split3_scalar(vy[u], hh, mm, ll);
+            Kys[(0 * WB + r) * KYW + c] = hh; Kys[(1 * WB + r) * KYW + c] = mm; Kys[(2 * WB + r) * KYW + c] = ll;
+        }
+    }
+    unsigned short* Ps = Pall + wave * (3 * 32 * KYW);
+    for (int i = lane; i < 3 * 32 * KYW / 2; i += 64) reinterpret_cast<unsigned*>(Ps)[i] = 0u;   // K padding stays zero
+    __syncthreads();
+
+    int soff[NQH], doff[NQH];
+    {
+        const int per_row = VEC ? W / 4 : W;
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int f = lane + 64 * q;
+            const int r = f / per_row, c = (f - r * per_row) * (VEC ? 4 : 1);
+            soff[q] = r < 32 ? r * W + c : -1;
+            doff[q] = r * KYW + c;
+        }
+    }
+    float pf[NPH];
+    auto prefetch = [&](const float* pg, int jt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const bool ok = soff[q] >= 0 && (jt * 32 + soff[q] / W) < H;
+            const int so = ok ? jt * 32 * W + soff[q] : 0;
+            if (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(pg + so);
+                pf[4 * q] = t.x; pf[4 * q + 1] = t.y; pf[4 * q + 2] = t.z; pf[4 * q + 3] = t.w;
+            } else {
+                pf[q] = pg[so];
+            }
+        }
+    };
+
+    const int c_begin = blockIdx.x * planes_per_block;
+    const float inv_cnt = 1.0f / (float)(H * W);
+    const long plane0 = ((long)b * a.heads + h) * C;
+    int c = c_begin + wave;
+    const int c_end = min(c_begin + planes_per_block, C);
+    if (c < c_end) prefetch(a.u + (plane0 + c) * H * W, 0);
+    // fragment base addresses (bytes)
+    const char* pa = reinterpret_cast<const char*>(Ps) + (l31 * KYW + 8 * kh) * 2;                  // + s*32*KYW*2 + t*32
+    const char* kyb = reinterpret_cast<const char*>(Kys) + (l31 * KYW + 8 * kh) * 2;                // + (s*WB + lt*32)*KYW*2 + t*32
+    const char* kxa = reinterpret_cast<const char*>(Kxs) + (l31 * KXW + 8 * kh) * 2;                // + (s*HB + it*32)*KXW*2 + (jt*32+16t')*2
+    for (; c < c_end; c += 4) {
+        f32x16 Yh[HT][WT], Yl[HT][WT];
+#pragma unroll
+        for (int i = 0; i < HT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { Yh[i][j][r] = 0.0f; Yl[i][j][r] = 0.0f; }
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt) {
+            // band jt: registers -> split -> this wave's private LDS band.  LDS operations of one wave execute in order.
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const bool ok = soff[q] >= 0 && (jt * 32 + soff[q] / W) < H;
+                if (soff[q] >= 0) {
+                    if (VEC) {
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split3_pair(ok ? pf[4 * q] : 0.0f, ok ? pf[4 * q + 1] : 0.0f, h0, m0, l0);
+                        split3_pair(ok ? pf[4 * q + 2] : 0.0f, ok ? pf[4 * q + 3] : 0.0f, h1, m1, l1);
+                        *reinterpret_cast<uint2*>(Ps + 0 * 32 * KYW + doff[q]) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(Ps + 1 * 32 * KYW + doff[q]) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2*>(Ps + 2 * 32 * KYW + doff[q]) = make_uint2(l0, l1);
+                    } else {
+                        unsigned short hh, mm, ll;
+                        split3_scalar(ok ? pf[q] : 0.0f, hh, mm, ll);
+                        Ps[0 * 32 * KYW + doff[q]] = hh; Ps[1 * 32 * KYW + doff[q]] = mm; Ps[2 * 32 * KYW + doff[q]] = ll;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (jt + 1 < HT) prefetch(a.u + (plane0 + c) * H * W, jt + 1);
+            else if (c + 4 < c_end) prefetch(a.u + (plane0 + c + 4) * H * W, 0);
+            // U[j][l] = sum_m P[j][m] Ky[l][m] for all WT column tiles at once: the P fragments are read once
+            // per k-step and consecutive MFMAs go to different accumulators (no dependent back-to-back issue)
+            f32x16 Uh[WT], Ul[WT];
+#pragma unroll
+            for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { Uh[lt][r] = 0.0f; Ul[lt][r] = 0.0f; }
+#pragma unroll
+            for (int t = 0; t < WB / 16; ++t) {
+                bf16x8 A[3], Bq[WT][3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    A[s] = *reinterpret_cast<const bf16x8*>(pa + s * (32 * KYW * 2) + t * 32);
+#pragma unroll
+                    for (int lt = 0; lt < WT; ++lt)
+                        Bq[lt][s] = *reinterpret_cast<const bf16x8*>(kyb + (s * WB + lt * 32) * (KYW * 2) + t * 32);
+                }
+#define LNS_SWU(ACC, SA, SB)                                                                          \
+    _Pragma("unroll") for (int lt = 0; lt < WT; ++lt)                                                 \
+        ACC[lt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], Bq[lt][SB], ACC[lt], 0, 0, 0);
+                LNS_SWU(Ul, 1, 1)
+                LNS_SWU(Uh, 0, 0)
+                LNS_SWU(Ul, 0, 2)
+                LNS_SWU(Ul, 2, 0)
+                LNS_SWU(Ul, 0, 1)
+                LNS_SWU(Ul, 1, 0)
+#undef LNS_SWU
+            }
+#pragma unroll
+            for (int lt = 0; lt < WT; ++lt) {
+                // split U in registers: k-step t' of the second product takes registers 8t'..8t'+7
+                uint4 Bu[2][3];
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    unsigned hq[4], mq[4], lq[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        split3_pair(Uh[lt][8 * tp + 2 * e] + Ul[lt][8 * tp + 2 * e],
+                                    Uh[lt][8 * tp + 2 * e + 1] + Ul[lt][8 * tp + 2 * e + 1], hq[e], mq[e], lq[e]);
+                    Bu[tp][0] = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+                    Bu[tp][1] = make_uint4(mq[0], mq[1], mq[2], mq[3]);
+                    Bu[tp][2] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+                }
+                // Y[i][l] += sum_{j in band} Kx[i][j] U[j][l], all HT row tiles per k-step (independent accumulators)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    bf16x8 A[HT][3], Bq[3];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                        for (int it = 0; it < HT; ++it)
+                            A[it][s] = *reinterpret_cast<const bf16x8*>(kxa + (s * HB + it * 32) * (KXW * 2) + (jt * 32 + 16 * tp) * 2);
+                        Bq[s] = __builtin_bit_cast(bf16x8, Bu[tp][s]);
+                    }
+#define LNS_SWY(ACC, SA, SB)                                                                          \
+    _Pragma("unroll") for (int it = 0; it < HT; ++it)                                                 \
+        ACC[it][lt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[it][SA], Bq[SB], ACC[it][lt], 0, 0, 0);
+                    LNS_SWY(Yl, 1, 1)
+                    LNS_SWY(Yh, 0, 0)
+                    LNS_SWY(Yl, 0, 2)
+                    LNS_SWY(Yl, 2, 0)
+                    LNS_SWY(Yl, 0, 1)
+                    LNS_SWY(Yl, 1, 0)
+#undef LNS_SWY
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < HT; ++it)
+#pragma unroll
+            for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Yh[it][lt][r] += Yl[it][lt][r];
+        float mean = 0.0f, rstd = 1.0f;
+        if (a.instnorm) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int it = 0; it < HT; ++it)
+#pragma unroll
+                for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool v = (it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W);
+                        sacc += v ? Yh[it][lt][r] : 0.0f;
+                    }
+            mean = wave_sum(sacc) * inv_cnt;
+            float q = 0.0f;
+#pragma unroll
+            for (int it = 0; it < HT; ++it)
+#pragma unroll
+                for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool v = (it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W);
+                        const float d = Yh[it][lt][r] - mean;
+                        q += v ? d * d : 0.0f;
+                    }
+            rstd = 1.0f / sqrtf(wave_sum(q) * inv_cnt + a.eps);
+        }
+        float* og = a.out + (plane0 + c) * H * W;
+#pragma unroll
+        for (int it = 0; it < HT; ++it)
+#pragma unroll
+            for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = it * 32 + drow(r, kh), l = lt * 32 + l31;
+                    if (i < H && l < W) og[i * W + l] = (Yh[it][lt][r] - mean) * rstd;
+                }
+    }
+}
+
+static size_t fa_sandwich_b_lds_bytes(int HT, int WT) {
+    const size_t HB = HT * 32, WB = WT * 32;
+    return (3 * HB * (HB + 8) + 3 * WB * (WB + 8) + 4 * 3 * 32 * (WB + 8)) * 2;
+}
+
 size_t fa_sandwich_lds_bytes(int H, int W) {
     const int HT = (H + 31) / 32, WT = (W + 31) / 32;
     const size_t HP = HT * 32 + 1, WP = WT * 32 + 1;
@@ -2183,6 +2438,18 @@ size_t fa_sandwich_lds_bytes(int H, int W) {
 
 template <int HT, int WT>
 static hipError_t launch_fa_sandwich_t(const FaSandwichArgs& a, hipStream_t s) {
+    // bf16x3 form whenever its LDS image fits (a function of H, W only, so the choice never depends on the batch)
+    static const bool fp32_only = getenv("LNS_FA_SANDWICH_FP32") != nullptr;
+    if (!fp32_only && fa_sandwich_b_lds_bytes(HT, WT) <= 160 * 1024) {
+        int ppb = 16;
+        while (ppb > 4 && (long)a.B * a.heads * ((a.C + ppb - 1) / ppb) < 512) ppb >>= 1;
+        dim3 grid((a.C + ppb - 1) / ppb, a.heads, a.B);
+        const size_t ldsb = fa_sandwich_b_lds_bytes(HT, WT);
+        const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.u) & 15) == 0);
+        if (vec) hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true>), grid, dim3(256), ldsb, s, a, ppb);
+        else hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, false>), grid, dim3(256), ldsb, s, a, ppb);
+        return hipGetLastError();
+    }
     const size_t lds = fa_sandwich_lds_bytes(a.H, a.W);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     // planes per block: enough blocks to fill the chip, few enough to amortise the Kx/Ky staging
@@ -2485,6 +2752,16 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 3, false, 8>))
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, true, 16>))
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, false, 16>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, true>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, false>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<1, 2, true>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<1, 2, false>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<2, 1, true>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<2, 1, false>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<2, 2, true>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<2, 2, false>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<2, 3, true>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<2, 3, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))

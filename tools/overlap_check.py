@@ -23,14 +23,22 @@ B = int(os.environ.get("BATCH", "64"))
 x = filler.normal("xfull", (B, args.in_channels, args.Ly, args.Lx), 5)
 xd = torch.from_numpy(x).cuda()
 eng = model._engine(xd)
+conditional = bool(getattr(model, "_conditional", False))
+pd = torch.linspace(0.1, 0.9, B, device="cuda").reshape(B, 1) if conditional else None
+
+
+def predict(inp, par):
+    return model.predict(inp, T, par, to_x=True) if conditional else model.predict(inp, T, to_x=True)
+
+
 # serial reference: the timing mode runs everything on one stream
 eng.timing_enable(True)
-ref = model.predict(xd, T, to_x=True).clone()
+ref = predict(xd, pd).clone()
 eng.timing_enable(False)
 torch.cuda.synchronize()
 bad = 0
 for r in range(R):
-    y = model.predict(xd, T, to_x=True)
+    y = predict(xd, pd)
     torch.cuda.synchronize()
     d = (y - ref).abs().amax(dim=(2, 3, 4))       # [B, T]
     nb = int((d > 0).sum().item())
@@ -46,6 +54,6 @@ for r in range(R):
             cols = wrong.any(0).any(0).nonzero().flatten().tolist()
             print("   sample %d frame %d: %d wrong values, channels %s, rows %s, cols %s" % (
                 bi, ti, int(wrong.sum()), wrong.any(2).any(1).nonzero().flatten().tolist(), rows[:12], cols[:40]))
-sub = model.predict(xd[10:12].contiguous(), T, to_x=True)
+sub = predict(xd[10:12].contiguous(), pd[10:12].contiguous() if conditional else None)
 print("sub-batch equals serial big:", torch.equal(sub, ref[10:12]))
 print("TOTAL_BAD", bad)

@@ -212,6 +212,15 @@ int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int
                          const float* cond, const float* freq_w_host, const float* freq_b_host,
                          const float* lin_w_host, const float* lin_b_host, float* y, void* stream);
 
+/* ---- "next row" (SURVEY 8f-2): the step right after the path -------------------------------------------------
+ * Fused denormalise + relative-L2 metric of a decoded rollout against the ground truth, one pass over both tensors:
+ *   yd = y*std + mean (dataset/ns2d_fno_stage2_simpleae.py:140-149), err = sqrt(sum (yhat_d - y_d)^2 / max(sum y_d^2, eps))
+ *   frame-wise over (H,W)   -> frame_out [B,T,C]   (relative_lp_loss(reduce_dim=(3,4)), training_utils.py:9-23,
+ *   sequence-wise over (T,H,W) -> seq_out [B,C]     (reduce_dim=(1,3,4)),                train_stage2_ns2d.py:254-257)
+ * yhat, y [B,T,C,H,W] device fp32 (normalised); scratch: device, >= B*T*C*2 floats; either output may be NULL. */
+int lns_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, int HW, float mean, float std, float eps,
+                      float* frame_out, float* seq_out, float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1580,6 +1580,13 @@ int lns_op_conv_pair_stress(int B, int H, int W, int cin_a, int cout_a, int ksiz
     return LNS_OK;
 }
 
+int lns_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, int HW, float mean, float std, float eps,
+                      float* frame_out, float* seq_out, float* scratch, void* stream) {
+    if (!yhat || !y || !scratch || B <= 0 || T <= 0 || C <= 0 || HW <= 0 || (!frame_out && !seq_out)) return LNS_EINVAL;
+    OPCHK(launch_metric_rel_l2(yhat, y, B, T, C, HW, mean, std, eps, frame_out, seq_out, scratch, static_cast<hipStream_t>(stream)));
+    return LNS_OK;
+}
+
 int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, float eps, const float* gamma_host,
                            const float* beta_host, const float* premul, float* ss, void* stream) {
     if (!x || !ss || C % groups) return LNS_EINVAL;

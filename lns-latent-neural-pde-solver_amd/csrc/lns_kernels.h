@@ -176,6 +176,10 @@ hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s);
 struct VecLinearArgs { const float* in; const float* w; const float* bias; float* out; int B, In, Out, ldi, ldo; };
 hipError_t launch_vec_linear(const VecLinearArgs& a, hipStream_t s);
 
+// fused denormalise + relative-L2 metric of a rollout (scratch: B*T*C*2 floats)
+hipError_t launch_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, int HW, float mean, float sd, float eps,
+                                float* frame_out, float* seq_out, float* scratch, hipStream_t s);
+
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
 
 }  // namespace lns

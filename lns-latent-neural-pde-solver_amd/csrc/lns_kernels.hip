@@ -2714,6 +2714,60 @@ hipError_t launch_vec_linear(const VecLinearArgs& a, hipStream_t s) {
 }
 
 // ===========================================================================
+// ===========================================================================
+// Fused denormalise + relative-L2 metric (the step after the path).  HBM-bound: one read of both
+// rollouts.  One block per (b, t, c) plane -> (sum of squared denormalised error, sum of squared denormalised
+// truth); a second tiny kernel forms the frame-wise and sequence-wise ratios.  Fixed reduction order.
+// ===========================================================================
+__global__ __launch_bounds__(256) void metric_plane_kernel(const float* yhat, const float* y, int HW, float mean, float sd,
+                                                           float* part) {
+    __shared__ float red[8];
+    const long plane = blockIdx.x;
+    const float* a = yhat + plane * HW;
+    const float* g = y + plane * HW;
+    float d2 = 0.0f, g2 = 0.0f;
+    const int n4 = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 ? HW / 4 : 0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 p = reinterpret_cast<const float4*>(a)[i], q = reinterpret_cast<const float4*>(g)[i];
+        const float e0 = (p.x - q.x) * sd, e1 = (p.y - q.y) * sd, e2 = (p.z - q.z) * sd, e3 = (p.w - q.w) * sd;
+        const float t0 = q.x * sd + mean, t1 = q.y * sd + mean, t2 = q.z * sd + mean, t3 = q.w * sd + mean;
+        d2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        g2 += (t0 * t0 + t1 * t1) + (t2 * t2 + t3 * t3);
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < HW; i += 256) {
+        const float e = (a[i] - g[i]) * sd, t = g[i] * sd + mean;
+        d2 += e * e; g2 += t * t;
+    }
+    d2 = wave_sum(d2); g2 = wave_sum(g2);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = d2; red[4 + (threadIdx.x >> 6)] = g2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[plane * 2] = (red[0] + red[1]) + (red[2] + red[3]);
+        part[plane * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+__global__ void metric_finish_kernel(const float* part, int B, int T, int C, float eps, float* frame_out, float* seq_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (b, c)
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    float sd = 0.0f, sg = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        const long p = ((long)b * T + t) * C + c;
+        const float d2 = part[p * 2], g2 = part[p * 2 + 1];
+        if (frame_out) frame_out[p] = sqrtf(d2 / (g2 < eps ? eps : g2));
+        sd += d2; sg += g2;
+    }
+    if (seq_out) seq_out[idx] = sqrtf(sd / (sg < eps ? eps : sg));
+}
+
+hipError_t launch_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, int HW, float mean, float sd, float eps,
+                                float* frame_out, float* seq_out, float* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(metric_plane_kernel, dim3((unsigned)((long)B * T * C)), dim3(256), 0, s, yhat, y, HW, mean, sd, scratch);
+    hipLaunchKernelGGL(metric_finish_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, scratch, B, T, C, eps, frame_out, seq_out);
+    return hipGetLastError();
+}
+
 hipError_t init_kernels() {
     hipError_t e;
     const int maxlds = 160 * 1024;

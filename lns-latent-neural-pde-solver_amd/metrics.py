@@ -1,0 +1,51 @@
+"""Validation-loop helpers next to the hot path: fused denormalise + relative-L2 metric, bulk
+dataset encode.  Mirrors the reference call sites:
+
+    y_hat = val_dataset.denormalize(model.predict(x, T, to_x=True)); y = val_dataset.denormalize(y)
+    frame_wise = relative_lp_loss(y_hat, y, reduce_dim=(3, 4), p=2)        # train_stage2_ns2d.py:253-257
+    seq_wise   = relative_lp_loss(y_hat, y, reduce_dim=(1, 3, 4), p=2)
+    dataset.encode_dataset(vq_ae, device)                                   # ns2d_fno_stage2_simpleae.py:81-93
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def relative_l2(y_hat, y, mean=0.0, std=1.0, eps=1e-8):
+    """(frame_wise [B,T,C], seq_wise [B,C]) relative L2 errors of a normalised rollout y_hat against the normalised
+    ground truth y, both [B,T,C,H,W], after the affine denormalisation x*std + mean.  One HIP pass over both
+    tensors (lns_metric_rel_l2); CPU tensors raise -- there is no CPU fallback."""
+    if not (y_hat.is_cuda and y.is_cuda):
+        raise RuntimeError("lns_amd.metrics.relative_l2 needs CUDA/HIP tensors (no CPU fallback)")
+    if y_hat.shape != y.shape or y_hat.dim() != 5:
+        raise ValueError("expected two [B,T,C,H,W] tensors of the same shape")
+    y_hat = y_hat.contiguous().float()
+    y = y.contiguous().float()
+    B, T, C, H, W = y.shape
+    frame = torch.empty((B, T, C), dtype=torch.float32, device=y.device)
+    seq = torch.empty((B, C), dtype=torch.float32, device=y.device)
+    scratch = torch.empty((B * T * C * 2,), dtype=torch.float32, device=y.device)
+    L = _lib.lib()
+    rc = L.lns_metric_rel_l2(y_hat.data_ptr(), y.data_ptr(), B, T, C, H * W, float(mean), float(std), float(eps),
+                             frame.data_ptr(), seq.data_ptr(), scratch.data_ptr(),
+                             ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("lns_metric_rel_l2 failed (rc=%d)" % rc)
+    return frame, seq
+
+
+@torch.no_grad()
+def encode_dataset(autoencoder, frames, chunk=32, mean=0.0, std=1.0, out_device="cpu"):
+    """Pre-encodes a whole trajectory set for stage-2 training: frames [N,C,H,W] (raw, un-normalised; torch tensor or
+    numpy array) -> latents [N, latent_dim, h, w], `chunk` frames per encoder call as the reference's datasets do,
+    with the dataset normalisation (u - mean) / (std + 1e-8) applied first."""
+    frames = torch.as_tensor(frames)
+    dev = next(iter(autoencoder.parameters())).device
+    outs = []
+    for s in range(0, frames.shape[0], chunk):
+        u = frames[s:s + chunk].to(dev, dtype=torch.float32)
+        u = (u - mean) / (std + 1e-8)
+        outs.append(autoencoder.encode(u).to(out_device))
+    return torch.cat(outs, 0)

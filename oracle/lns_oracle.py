@@ -608,3 +608,36 @@ class OracleDynamics:
         if return_latents:
             return out, np.stack(lat, axis=1)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# "next rows" (SURVEY 8f): denormalise + relative_lp_loss, bulk encode
+# ---------------------------------------------------------------------------------------------------
+def relative_lp_loss(pred, gt, reduce_dim, eps=1e-8):
+    """training_utils.py:9-23 with p=2, reduction='sum', reduce_all=False (float64 accumulation)."""
+    pred = np.asarray(pred, np.float64)
+    gt = np.asarray(gt, np.float64)
+    gt_norm = (gt ** 2).sum(axis=reduce_dim)
+    gt_norm = np.where(gt_norm < eps, eps, gt_norm)
+    diff = ((pred - gt) ** 2).sum(axis=reduce_dim)
+    return np.sqrt(diff / gt_norm)
+
+
+def denormalize(x, mean, std):
+    """dataset/ns2d_fno_stage2_simpleae.py:140-149 (affine, scalar stats)."""
+    return np.asarray(x, np.float64) * std + mean
+
+
+def rollout_metrics(y_hat, y, mean=0.0, std=1.0, eps=1e-8):
+    """The validate_loop metric pair of train_stage2_ns2d.py:253-257 on [B,T,C,H,W] arrays."""
+    yh, yt = denormalize(y_hat, mean, std), denormalize(y, mean, std)
+    return relative_lp_loss(yh, yt, (3, 4), eps), relative_lp_loss(yh, yt, (1, 3, 4), eps)
+
+
+def encode_dataset(ae, frames, chunk=32, mean=0.0, std=1.0):
+    """ns2d_fno_stage2_simpleae.py:81-93: normalise, encode `chunk` frames at a time."""
+    outs = []
+    for s in range(0, frames.shape[0], chunk):
+        u = (frames[s:s + chunk].astype(np.float32) - np.float32(mean)) / (np.float32(std) + np.float32(1e-8))
+        outs.append(ae.encode(u.astype(np.float32)))
+    return np.concatenate(outs, 0)

@@ -213,3 +213,46 @@ def test_full_size_rollout_properties():
     assert torch.equal(y[10:12], sub)
     ref = orc.predict(x[10:12], 4, to_x=True)
     assert rel_l2(sub.cpu().numpy(), ref) < STAGE_TOL * 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# "next rows" (SURVEY 8f): fused denormalise + relative-L2 metric, bulk dataset encode
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 5, 3, 32, 32), (2, 4, 5, 24, 48), (2, 3, 2, 61, 121), (1, 2, 3, 7, 9)])
+def test_metric_rel_l2_matches_oracle(shape):
+    """lns_metric_rel_l2 vs the oracle restatement of denormalize + relative_lp_loss (frame- and sequence-wise),
+    including a plane whose ground truth is ~0 (the eps clamp)."""
+    _need_gpu()
+    import lns_oracle
+    from lns_amd import metrics
+    r = np.random.default_rng(3)
+    y = r.standard_normal(shape).astype(np.float32)
+    yh = (y + 0.05 * r.standard_normal(shape)).astype(np.float32)
+    mean, std = 0.37, 1.9
+    y[0, 0, 0] = -mean / std                     # denormalises to ~0 -> the eps clamp path
+    f_ref, s_ref = lns_oracle.rollout_metrics(yh, y, mean, std)
+    f, s = metrics.relative_l2(torch.from_numpy(yh).cuda(), torch.from_numpy(y).cuda(), mean, std)
+    f, s = f.cpu().numpy().astype(np.float64), s.cpu().numpy().astype(np.float64)
+    big = f_ref > 1e3                            # clamp-dominated entries: compare in log scale
+    assert np.allclose(f[~big], f_ref[~big], rtol=2e-5, atol=1e-7)
+    assert np.allclose(np.log(f[big]), np.log(f_ref[big]), rtol=1e-2) if big.any() else True
+    assert np.allclose(s, s_ref, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_encode_dataset_matches_oracle():
+    """Bulk pre-encoding (chunks of frames through the encoder, dataset normalisation applied first)."""
+    _need_gpu()
+    import gpu_checks as gc
+    import lns_oracle
+    from lns_amd import config, filler, metrics
+    args = config.preset("ns2d_mini")
+    model, orc = gc.build_models(args, 1)
+    frames = filler.normal("frames", (11, args.in_channels, args.Ly, args.Lx), 9) * 2.0 + 0.3
+    z = metrics.encode_dataset(model.vq_ae, frames, chunk=4, mean=0.3, std=2.0).numpy()
+    ref = lns_oracle.encode_dataset(orc.ae, frames, chunk=4, mean=0.3, std=2.0)
+    assert z.shape == ref.shape
+    assert rel_l2(z, ref) < STAGE_TOL
+    with pytest.raises(RuntimeError):
+        metrics.relative_l2(torch.zeros(1, 1, 1, 2, 2), torch.zeros(1, 1, 1, 2, 2))

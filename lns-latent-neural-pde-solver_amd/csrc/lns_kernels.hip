@@ -1421,35 +1421,78 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsArgs a) {
     const long n = (long)cg * a.HW;
     const float* xs = a.x + (long)b * a.x_bs + (long)g * cg * a.HW;
     const float* pm = a.premul ? a.premul + (long)b * a.C + g * cg : nullptr;
-    float s = 0.0f;
-    if (!pm && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15) == 0)) {
+    float s = 0.0f, q = 0.0f;
+    float mean;
+    const bool vec = !pm && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15) == 0);
+    constexpr int NV = 32;                                  // float4 per thread held in registers
+    if (vec && (n >> 2) <= (long)NV * 256) {
+        // the whole slab fits the block's registers: ONE read (all loads in flight), exact two-pass statistics,
+        // the same per-thread element order and reduction tree as the streaming path below
         const float4* x4 = reinterpret_cast<const float4*>(xs);
-        for (long i = threadIdx.x; i < (n >> 2); i += 256) {
-            const float4 v = x4[i];
-            s += (v.x + v.y) + (v.z + v.w);
+        const int n4 = (int)(n >> 2);
+        float4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = threadIdx.x + u * 256;
+            v[u] = i < n4 ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+            if (threadIdx.x + u * 256 < n4) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        mean = block_sum_256(s, red) / (float)n;
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+            if (threadIdx.x + u * 256 < n4) {
+                const float d0 = v[u].x - mean, d1 = v[u].y - mean, d2 = v[u].z - mean, d3 = v[u].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
     } else {
-        for (long i = threadIdx.x; i < n; i += 256) {
-            float v = xs[i];
-            if (pm) v *= pm[i / a.HW];
-            s += v;
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xs);
+            const long n4 = n >> 2;
+            for (long base = 0; base < n4; base += 256 * 8) {       // 8 loads in flight per thread
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long i = base + threadIdx.x + u * 256;
+                    v[u] = i < n4 ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (base + threadIdx.x + u * 256 < n4) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            }
+        } else {
+            for (long i = threadIdx.x; i < n; i += 256) {
+                float v = xs[i];
+                if (pm) v *= pm[i / a.HW];
+                s += v;
+            }
         }
-    }
-    const float mean = block_sum_256(s, red) / (float)n;
-    float q = 0.0f;
-    if (!pm && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15) == 0)) {
-        const float4* x4 = reinterpret_cast<const float4*>(xs);
-        for (long i = threadIdx.x; i < (n >> 2); i += 256) {
-            const float4 v = x4[i];
-            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-    } else {
-        for (long i = threadIdx.x; i < n; i += 256) {
-            float v = xs[i];
-            if (pm) v *= pm[i / a.HW];
-            const float d = v - mean;
-            q += d * d;
+        mean = block_sum_256(s, red) / (float)n;
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xs);
+            const long n4 = n >> 2;
+            for (long base = 0; base < n4; base += 256 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long i = base + threadIdx.x + u * 256;
+                    v[u] = i < n4 ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (base + threadIdx.x + u * 256 < n4) {
+                        const float d0 = v[u].x - mean, d1 = v[u].y - mean, d2 = v[u].z - mean, d3 = v[u].w - mean;
+                        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                    }
+            }
+        } else {
+            for (long i = threadIdx.x; i < n; i += 256) {
+                float v = xs[i];
+                if (pm) v *= pm[i / a.HW];
+                const float d = v - mean;
+                q += d * d;
+            }
         }
     }
     const float var = block_sum_256(q, red) / (float)n;
@@ -1529,8 +1572,13 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnStatsArgs a, const fl
 }
 
 bool gn_stats_two_stage(const GnStatsArgs& a) {
-    // depends on the layer only, never on the batch: results stay bit-identical across batch sizes
-    return a.C / a.groups >= 32;
+    // depends on the layer only, never on the batch: results stay bit-identical across batch sizes.
+    // Wide groups go through per-channel partials + a merge, unless the whole group slab fits the registers of one
+    // block (<= 128 KB, no per-channel pre-multiplier): then the single-read path of gn_stats_kernel is one launch.
+    if (a.C / a.groups < 32) return false;
+    const long n = (long)(a.C / a.groups) * a.HW;
+    const bool in_regs = !a.premul && (n & 3) == 0 && (n >> 2) <= 32 * 256 && (a.x_bs & 3) == 0;
+    return !in_regs;
 }
 
 hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s) {

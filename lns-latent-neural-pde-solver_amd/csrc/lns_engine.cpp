@@ -100,7 +100,7 @@ struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Ho
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
                           int kc_log2_pack, int Cout_pad, int force_variant, bool need_wgm1 = false,
-                          bool allow_bf16x3 = false, int Cin = 1 << 30) {
+                          bool allow_bf16x3 = false, int Cin = 1 << 30, bool f16x2 = false) {
     g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
     g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
     if (g.Hout <= 0 || g.Wout <= 0) return false;
@@ -116,7 +116,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
     static const bool no_bf16x3 = getenv("LNS_CONV_FP32_MFMA") != nullptr;
     const bool use_b = allow_bf16x3 && !no_bf16x3 && k == 3 && stride == 1 && Cout > 32;
     if (force_variant < 0 && use_b) {   // fp32 variants only if the geometry rules the bf16x3 tiles out
-        cands.insert(cands.begin(), (int)CV_B64);
+        cands.insert(cands.begin(), f16x2 ? (int)CV_F64 : (int)CV_B64);
     }
     static const bool no_b1 = getenv("LNS_CONV1_FP32_MFMA") != nullptr;
     // 1x1: bf16x3 unless the layer is a thin projection (few output channels / a handful of input channels:
@@ -326,7 +326,7 @@ struct Planner {
         if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
         const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
         ConvGeom g;
-        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb, pk.cin))
+        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb, pk.cin, pk.f16))
             throw std::runtime_error("no conv tiling for " + name);
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
@@ -370,6 +370,7 @@ struct Planner {
         if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
+        a.unscale = g.variant == CV_F64 ? 1.0f / (16.0f * pk.wscale) : 1.0f;
         a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.sel_kc_log2;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
@@ -772,12 +773,26 @@ static int finalize_weights(lns_engine* e, int device) {
     }
     for (VecPack& v : e->vecs) { v.off = off; off += round_up_sz(v.count, 64); }
     std::vector<float> host(off, 0.0f);
+    // 3x3 convs: two-term fp16 split (f16x2) unless LNS_CONV3_SPLIT=bf16x3; the weight scale is the power of two
+    // that brings the largest |w| of the layer just below 2^14
+    static const bool conv3_f16 = !(getenv("LNS_CONV3_SPLIT") && strcmp(getenv("LNS_CONV3_SPLIT"), "bf16x3") == 0);
+    for (ConvPack& p : e->packs) {
+        p.f16 = false; p.wscale = 1.0f;
+        if (!(p.has_wb && p.k == 3 && conv3_f16)) continue;
+        float mx = 0.0f;
+        for (const std::string& key : p.wkeys)
+            for (float v : e->params[e->pindex.at(key)].host) mx = std::max(mx, fabsf(v));
+        if (!(mx > 0.0f) || !std::isfinite(mx)) continue;          // all-zero / non-finite weights: keep bf16x3
+        p.f16 = true;
+        p.wscale = exp2f(floorf(log2f(16000.0f / mx)));
+    }
     for (const ConvPack& p : e->packs) {
         int co = 0;
         for (size_t i = 0; i < p.wkeys.size(); ++i) {
             const Param& w = e->params[e->pindex.at(p.wkeys[i])];
             pack_conv_weight(host.data() + p.w_off, w.host.data(), co, p.couts[i], p.cin, p.k, p.Cin_pad, p.Cout_pad);
-            if (p.has_wb && p.k == 3) convb_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
+            if (p.has_wb && p.k == 3 && !p.f16) convb_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
+            if (p.has_wb && p.k == 3 && p.f16) convf_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad, p.wscale);
             if (p.has_wb && p.k == 1) convb1_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
             if (!p.bkeys[i].empty()) {
                 const Param& b = e->params[e->pindex.at(p.bkeys[i])];
@@ -1449,11 +1464,18 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     std::vector<float> hw(wcount + pk.Cout_pad, 0.0f);
     pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
     if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
-    const size_t wb_floats = (g.variant == CV_B64 || g.variant == CV_B32) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
+    float wscale = 1.0f;
+    if (g.variant == CV_F64) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < (size_t)Cout * Cin * 9; ++i) mx = std::max(mx, fabsf(w_host[i]));
+        if (mx > 0.0f) wscale = exp2f(floorf(log2f(16000.0f / mx)));
+    }
+    const size_t wb_floats = (g.variant == CV_B64 || g.variant == CV_B32 || g.variant == CV_F64) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
                            : g.variant == CV_B1 ? convb1_weight_bytes(Cout, pk.Cin_pad) / 4 : 0;
     if (wb_floats) {
         hw.resize(hw.size() + wb_floats, 0.0f);
-        if (g.variant != CV_B1) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
+        if (g.variant == CV_F64) convf_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
+        else if (g.variant != CV_B1) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
         else convb1_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
     }
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dw), hw.size() * 4));
@@ -1471,6 +1493,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
+    a.unscale = g.variant == CV_F64 ? 1.0f / (16.0f * wscale) : 1.0f;
     a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
     a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;

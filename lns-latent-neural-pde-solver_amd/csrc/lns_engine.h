@@ -28,7 +28,8 @@ struct ConvPack {
     bool has_bias = false;
     int Cin_pad = 0, Cout_pad = 0, kc_log2 = 3;
     size_t w_off = 0, b_off = 0;      // float offsets in the device weight blob
-    size_t wb_off = 0; bool has_wb = false;   // bf16x3 slabs (3x3 only)
+    size_t wb_off = 0; bool has_wb = false;   // bf16x3 / f16x2 slabs
+    bool f16 = false; float wscale = 1.0f;    // 3x3: slabs hold the two-term fp16 split of w * wscale
 };
 
 enum VecXform { VX_NONE = 0, VX_TRANSPOSE2D = 1, VX_PE_T = 2 };

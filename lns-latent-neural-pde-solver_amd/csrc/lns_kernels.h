@@ -42,6 +42,7 @@ struct ConvArgs {
     // bf16x3 path (3x3, stride 1): weights pre-split into 3 bf16 terms,
     // layout [cout tile][stage of 8 ch][split 3][tap 9][64 cout][8 ch]
     const void* wb;
+    float unscale;         // accumulator scale of the bf16x3 / f16x2 epilogue: 1, or 1 / (16 * weight scale) for the fp16 form
     int ct_per_block;      // 1x1 bf16x3, input-stationary form: cout tiles walked by one block (0 = streaming form)
     int B;
 };
@@ -49,7 +50,8 @@ struct ConvArgs {
 // tile variants: (TM couts x TN pixels) per 256-thread block
 enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4, CV_S32 = 5, CV_COUNT = 6,
                    CV_B64 = 6 /* bf16x3 3x3 kernel */, CV_B1 = 7 /* bf16x3 1x1 kernel */,          // both 64 couts x 128 pixels
-                   CV_B32 = 9 /* bf16x3 3x3 kernel, 32 couts x 128 pixels (same bits as CV_B64) */ };
+                   CV_B32 = 9 /* bf16x3 3x3 kernel, 32 couts x 128 pixels (same bits as CV_B64) */,
+                   CV_F64 = 11 /* 3x3 kernel with the two-term fp16 split (f16x2), 64 couts x 128 pixels */ };
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
 size_t conv_lds_bytes(int variant, const ConvArgs& a);
@@ -59,12 +61,13 @@ hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 // 3x3 convolution on bf16 MFMA with every fp32 operand split into three bf16 terms (6 products,
 // two accumulators): fp32-level accuracy at 2.7x the fp32-MFMA rate.  Tile 64 couts x 128 pixels.
 #define CONVB_SLAB_BYTES 27648           // one (cout tile, stage) weight slab: 3 splits x 9 taps x 64 couts x 8 ch bf16
-size_t convb_lds_bytes(const ConvArgs& a, int tile_couts);
+size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits);
 bool convb_fits(const ConvArgs& a);
 hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s);
 // host-side packing of one [Cout][Cin][3][3] weight (cout offset co0 inside the pack) into the bf16x3 slab layout
 size_t convb_weight_bytes(int Cout, int Cin_pad);
 void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);
+void convf_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale);   // f16x2 slabs
 // 1x1 bf16x3 kernel: slabs [cout tile][stage of 32 ch][split 3][octet 4][64 cout][8 ch], Cin_pad % 32 == 0
 size_t convb1_lds_bytes(const ConvArgs& a);
 bool convb1_fits(const ConvArgs& a);

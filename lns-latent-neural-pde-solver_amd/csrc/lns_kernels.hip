@@ -466,7 +466,7 @@ int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
 static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8 : CONV_MAXE3) : CONV_MAXE1; }
 
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
-    if (variant == CV_B64 || variant == CV_B32) return convb_lds_bytes(a, variant == CV_B32 ? 32 : 64);
+    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return convb_lds_bytes(a, variant == CV_B32 ? 32 : 64, variant == CV_F64 ? 2 : 3);
     if (variant == CV_B1) return convb1_lds_bytes(a);
     const int KC = 1 << a.kc_log2;
     const int TM = kConvInfo[variant].TM;
@@ -476,7 +476,7 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 }
 
 bool conv_fits(int variant, const ConvArgs& a) {
-    if (variant == CV_B64 || variant == CV_B32) return convb_fits(a);
+    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return convb_fits(a);
     if (variant == CV_B1) return convb1_fits(a);
     const long KC = 1 << a.kc_log2;
     const int TN = kConvInfo[variant].TN;
@@ -509,7 +509,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 }
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
-    if (variant == CV_B64 || variant == CV_B32) return launch_conv_bf16x3(variant, a, s);
+    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return launch_conv_bf16x3(variant, a, s);
     if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
     if (!conv_fits(variant, a)) return hipErrorInvalidValue;
     const size_t lds = conv_lds_bytes(variant, a);
@@ -562,6 +562,18 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned& h, unsig
     l = pk_bf16(rx - __uint_as_float(m << 16), ry - __uint_as_float(m & 0xffff0000u));
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two fp32 values -> packed (h, l) fp16 pairs with x = h + l to ~23 bits (RNE: v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, unsigned& l) {
+    const f32x2 v = {x, y};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const f32x2 hb = __builtin_convertvector(hh, f32x2);
+    const f32x2 r = {x - hb[0], y - hb[1]};
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
 // Shared epilogue of the bf16x3 kernels (64-cout tile, wave = 64 couts x 32*NT pixels): sums the two
 // accumulators, then bias / per-sample add / activation / fused second 1x1 conv (fp32 MFMA, the
 // accumulator tile as B operand, see conv_mfma_kernel) / residual, and the coalesced stores.
@@ -577,7 +589,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc_hi[mt][nt][r] + acc_lo[mt][nt][r];
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r]) * a.unscale;   // power of two
     const int HWo = a.Hout * a.Wout;
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
@@ -663,18 +675,22 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     }
 }
 
-template <int NT, int NU, bool FUSE2, int MT = 2>
+template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
+    // SPL = 3: three bf16 terms, six products.  SPL = 2: two fp16 terms of the operand scaled by a power of two
+    // (activations x16 in the staging, weights per layer on the host), three products hh' + (hl' + lh'); the
+    // dropped ll' term is <= 2^-24 |xy|.  Half the MFMAs and 2/3 of the LDS bytes at the accuracy of an fp32 chain.
     // MT = 1: 32-cout tiles (half a weight slab per block).  Same accumulation order, so the planner may pick it
     // freely; it is used when 64-cout tiles would leave CUs with fewer than two blocks.
     constexpr int NTHR = 256, TM = 32 * MT, TN = 128 * NT, KC = 8, NJ = 5;
-    constexpr int SLAB = CONVB_SLAB_BYTES * MT / 2;       // bytes of weights per stage in LDS
+    constexpr int SLAB64 = CONVB_SLAB_BYTES * SPL / 3;    // host slab of a 64-cout tile, one stage
+    constexpr int SLAB = SLAB64 * MT / 2;                 // bytes of weights per stage in LDS
     constexpr int NWU = (SLAB / 16 + NTHR - 1) / NTHR;    // weight 16-byte units per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int PH = a.PH, PW = a.PW;
     const int PLANE = PH * PW;
     const int PP1 = PLANE + 1;                         // plane stride in units; unit PLANE = write sink
-    const int xb_bytes = 3 * PP1 * 16;
+    const int xb_bytes = SPL * PP1 * 16;
     const int buf_bytes = xb_bytes + SLAB;
     char* lds = smem;                                                  // 2 x [Xb | Wb]
     char* zunit = lds + 2 * buf_bytes;                                 // one all-zero 16-byte unit
@@ -716,12 +732,12 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             if (sy >= 0 && sx >= 0) d = sy * a.Win + sx;
         }
         udm[u] = d >= 0 ? d : 0;
-        uok[u] = d >= 0 ? 1.0f : 0.0f;
+        uok[u] = d >= 0 ? (SPL == 2 ? 16.0f : 1.0f) : 0.0f;     // fp16 split: activations are staged x16
         uslot[u] = (p < PLANE ? p : PLANE) * 16;
     }
     // weight slab of this cout tile: host slabs hold 64 couts per (split, tap) row; a 32-cout block copies its half
     // of every row.  16 bytes per thread-slot.
-    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * CONVB_SLAB_BYTES +
+    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * SLAB64 +
                         (MT == 1 ? (ct & 1) * 512 : 0);
 
     // per-lane operand offsets (bytes).  K of one MFMA = 2 taps x 8 channels: lane half kh takes tap 2j+kh.
@@ -777,19 +793,20 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             if (MODE == 2) v = swish_fast(v);
             t[e] = v * uok[u];
         }
-        split3_pair(t[0], t[1], hq[u][cp], mq[u][cp], lq[u][cp]);
+        if (SPL == 3) split3_pair(t[0], t[1], hq[u][cp], mq[u][cp], lq[u][cp]);
+        else split2_pair_f16(t[0], t[1], hq[u][cp], mq[u][cp]);
     };
     auto flush_unit = [&](int u, char* Xn) __attribute__((always_inline)) {
         char* dst = Xn + uslot[u];
         *reinterpret_cast<uint4*>(dst) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
         *reinterpret_cast<uint4*>(dst + PP1 * 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
-        *reinterpret_cast<uint4*>(dst + 2 * PP1 * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
+        if (SPL == 3) *reinterpret_cast<uint4*>(dst + 2 * PP1 * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
     };
     auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
         const int idx = tid + i * NTHR;                  // 16-byte unit inside the slab
         const int off = idx < SLAB / 16 ? idx : SLAB / 16 - 1;
         const int src = MT == 1 ? (off >> 5) * 1024 + (off & 31) * 16 : off * 16;     // row of 64 couts -> its 32
-        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB_SLAB_BYTES + src);
+        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * SLAB64 + src);
         wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
     };
     auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
@@ -799,18 +816,18 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     };
 
     // fragments of k-step j: A[s][mt] (couts), B[s][nt] (pixels), s = h / m / l
-    auto load_frags = [&](int j, const char* Xs, const char* Ws, bf16x8 (&af)[3][MT], bf16x8 (&bf)[3][NT])
+    auto load_frags = [&](int j, const char* Xs, const char* Ws, uint4 (&af)[SPL][MT], uint4 (&bf)[SPL][NT])
                           __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < SPL; ++s) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                af[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + s * (9 * TM * 16) + mt * (32 * 16) + aoff[j]);
+                af[s][mt] = *reinterpret_cast<const uint4*>(Ws + s * (9 * TM * 16) + mt * (32 * 16) + aoff[j]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const char* p = Xs + s * PP1 * 16 + boff[nt] + ltoff[j];
                 if (j == NJ - 1) p = ztap ? zunit : p;
-                bf[s][nt] = *reinterpret_cast<const bf16x8*>(p);
+                bf[s][nt] = *reinterpret_cast<const uint4*>(p);
             }
         }
     };
@@ -854,7 +871,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             char* Wn = Xn + xb_bytes;
             const int cw = c0 + KC < last ? c0 + KC : last;
             const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
-            bf16x8 af[2][3][MT], bf[2][3][NT];
+            uint4 af[2][SPL][MT], bf[2][SPL][NT];
             load_frags(0, Xs, Ws, af[0], bf[0]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -865,13 +882,22 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #define LNS_BX3(ACC, SA, SB)                                                                          \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
-            ACC[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA][mt], Bq[SB][nt], ACC[mt][nt], 0, 0, 0);
-                LNS_BX3(acc_lo, 1, 1)
-                LNS_BX3(acc_hi, 0, 0)
-                LNS_BX3(acc_lo, 0, 2)
-                LNS_BX3(acc_lo, 2, 0)
-                LNS_BX3(acc_lo, 0, 1)
-                LNS_BX3(acc_lo, 1, 0)
+            ACC[mt][nt] = SPL == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA][mt]),          \
+                                         __builtin_bit_cast(bf16x8, Bq[SB][nt]), ACC[mt][nt], 0, 0, 0)                       \
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA][mt]),            \
+                                         __builtin_bit_cast(f16x8, Bq[SB][nt]), ACC[mt][nt], 0, 0, 0);
+                if (SPL == 3) {
+                    LNS_BX3(acc_lo, 1, 1)
+                    LNS_BX3(acc_hi, 0, 0)
+                    LNS_BX3(acc_lo, 0, SPL - 1)
+                    LNS_BX3(acc_lo, SPL - 1, 0)
+                    LNS_BX3(acc_lo, 0, 1)
+                    LNS_BX3(acc_lo, 1, 0)
+                } else {
+                    LNS_BX3(acc_hi, 0, 0)
+                    LNS_BX3(acc_lo, 0, 1)
+                    LNS_BX3(acc_lo, 1, 0)
+                }
 #undef LNS_BX3
                 if (j < 4) {
 #pragma unroll
@@ -885,10 +911,10 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                 }
                 // interleave: after each MFMA a few of the step's other instructions
 #pragma unroll
-                for (int g = 0; g < 6 * MT * NT; ++g) {
+                for (int g = 0; g < (SPL == 3 ? 6 : 3) * MT * NT; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x100, SPL == 3 ? 1 : 2, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, SPL == 3 ? 5 : 8, 0);   // VALU
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
                 }
@@ -1321,18 +1347,75 @@ hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-size_t convb_lds_bytes(const ConvArgs& a, int tm) {
+size_t convb_lds_bytes(const ConvArgs& a, int tm, int spl) {
     const size_t pp1 = (size_t)a.PH * a.PW + 1;
-    return 2 * (3 * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
+    return 2 * (spl * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
 }
 
 bool convb_fits(const ConvArgs& a) {
     return a.ks == 3 && a.stride == 1 && (a.Cin_pad % 8) == 0 && a.wb != nullptr &&
-           (long)a.PH * a.PW <= CONVB_MAXU * 256 && convb_lds_bytes(a, 64) <= 150 * 1024;
+           (long)a.PH * a.PW <= CONVB_MAXU * 256 && convb_lds_bytes(a, 64, 3) <= 150 * 1024;
 }
 
 size_t convb_weight_bytes(int Cout, int Cin_pad) {
-    return (size_t)((Cout + 63) / 64) * (Cin_pad / 8) * CONVB_SLAB_BYTES;
+    return (size_t)((Cout + 63) / 64) * (Cin_pad / 8) * CONVB_SLAB_BYTES;     // the fp16 form needs 2/3 of it
+}
+
+// fp32 -> fp16 bits, round to nearest even, subnormals and overflow handled (host side of the f16x2 scheme)
+static inline uint16_t host_f16_rne(float x, float* back) {
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t m = u & 0x7fffffu;
+    uint16_t hbits;
+    if (((u >> 23) & 0xff) == 0xff) hbits = (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+    else if (e >= 31) hbits = (uint16_t)(sign | 0x7c00u);
+    else if (e <= 0) {
+        if (e < -10) hbits = (uint16_t)sign;
+        else {
+            m |= 0x800000u;
+            const int shift = 14 - e;                     // 14..24
+            const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+            hbits = (uint16_t)(sign | (q + ((rem > halfway || (rem == halfway && (q & 1))) ? 1 : 0)));
+        }
+    } else {
+        const uint32_t q = m >> 13, rem = m & 0x1fffu;
+        uint32_t v = ((uint32_t)e << 10) | q;
+        if (rem > 0x1000u || (rem == 0x1000u && (q & 1))) ++v;   // may carry into the exponent (correct)
+        hbits = (uint16_t)(sign | v);
+    }
+    // back-conversion
+    const uint32_t he = (hbits >> 10) & 0x1f, hm = hbits & 0x3ff;
+    float f;
+    if (he == 0) f = (float)hm * 5.9604644775390625e-8f;                       // 2^-24
+    else if (he == 31) f = __builtin_inff();
+    else { const uint32_t fu = ((he - 15 + 127) << 23) | (hm << 13); __builtin_memcpy(&f, &fu, 4); }
+    *back = (hbits & 0x8000u) ? -f : f;
+    return hbits;
+}
+
+// f16x2 slabs: [cout tile 64][stage of 8 ch][split 2][tap 9][64 cout][8 ch] fp16 of w * wscale (wscale: power of two)
+void convf_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale) {
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    const int nstage = Cin_pad / 8;
+    for (int co = 0; co < cout; ++co) {
+        const int cog = co0 + co, ct = cog / 64, cl = cog % 64;
+        for (int ci = 0; ci < cin; ++ci) {
+            const int st = ci / 8, c = ci % 8;
+            for (int t = 0; t < 9; ++t) {
+                const float v = w[((size_t)co * cin + ci) * 9 + t] * wscale;
+                float hb, lb;
+                uint16_t q[2];
+                q[0] = host_f16_rne(v, &hb);
+                q[1] = host_f16_rne(v - hb, &lb);
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const size_t unit = (((size_t)ct * nstage + st) * 2 + sidx) * 9 + t;
+                    d[(unit * 64 + cl) * 8 + c] = q[sidx];
+                }
+            }
+        }
+    }
 }
 
 static inline uint16_t host_bf16_rne(float x, float* back) {
@@ -1392,14 +1475,25 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     if (!convb_fits(a)) return hipErrorInvalidValue;
     dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
     const bool two = (long)a.PH * a.PW > 256;            // patch units per thread
+    if (variant == CV_F64) {                              // two-term fp16 split
+        const size_t lds = convb_lds_bytes(a, 64, 2);
+        if (a.w2) {
+            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true, 2, 2>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true, 2, 2>), grid, dim3(256), lds, s, a);
+        } else {
+            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 2, 2>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 2, 2>), grid, dim3(256), lds, s, a);
+        }
+        return hipGetLastError();
+    }
     if (variant == CV_B32) {                              // 32-cout tiles: a.cout_tiles counts those
         if (a.w2) return hipErrorInvalidValue;
-        const size_t lds = convb_lds_bytes(a, 32);
+        const size_t lds = convb_lds_bytes(a, 32, 3);
         if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 1>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 1>), grid, dim3(256), lds, s, a);
         return hipGetLastError();
     }
-    const size_t lds = convb_lds_bytes(a, 64);
+    const size_t lds = convb_lds_bytes(a, 64, 3);
     if (a.w2) {
         if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true>), grid, dim3(256), lds, s, a);
@@ -2880,6 +2974,10 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv1_bf16x3_kernel<true, false>))
     LNS_SET_LDS((conv1_bf16x3_kernel<false, true>))
     LNS_SET_LDS((conv1_bf16x3_kernel<false, false>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 2, 2>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true, 2, 2>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 1>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 1>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true>))

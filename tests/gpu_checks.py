@@ -120,6 +120,7 @@ for _c in [dict(B=2, Cin=64, Cout=64, H=32, W=32, mode=(1, 1)), dict(B=2, Cin=64
            dict(B=2, Cin=128, Cout=128, H=16, W=16, ss=True, act_in=1, act_out=2, badd=True),
            dict(B=2, Cin=40, Cout=72, H=20, W=36, mode=(0, 0)), dict(B=1, Cin=512, Cout=64, H=32, W=32, mode=(1, 1), ss=True)]:
     CONV_CASES.append(dict(k=3, variant=6, **_c))
+    CONV_CASES.append(dict(k=3, variant=11, **_c))        # two-term fp16 split (f16x2) of the same kernel
     if not (_c.get('Cout') == 64 and _c.get('Cin') == 512):
         CONV_CASES.append(dict(k=3, variant=9, **_c))     # 32-cout tiles of the same kernel
 # bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel

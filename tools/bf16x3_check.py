@@ -42,7 +42,9 @@ if __name__ == "__main__":
              (2, 64, 64, 24, 48, 1, (0, 1)), (2, 128, 128, 12, 24, 3, (0, 1)), (1, 64, 64, 128, 128, 1, (1, 1)),
              (2, 40, 72, 20, 36, 1, (0, 0))]
     for c in cases:
-        for scale in (1.0, 1e3):
+        for scale in (1.0, 1e-3, 100.0):
             e1 = run(*c, variant=1, scale=scale)
             e6 = run(*c, variant=6, scale=scale)
-            print("case %s scale %g: fp32-mfma rel %.3e max %.3e | bf16x3 rel %.3e max %.3e" % (c, scale, e1[0], e1[1], e6[0], e6[1]), flush=True)
+            e11 = run(*c, variant=11, scale=scale)
+            print("case %s scale %g: fp32-mfma rel %.3e max %.3e | bf16x3 rel %.3e max %.3e | f16x2 rel %.3e max %.3e" % (
+                c, scale, e1[0], e1[1], e6[0], e6[1], e11[0], e11[1]), flush=True)

@@ -370,7 +370,7 @@ struct Planner {
         if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
-        a.unscale = g.variant == CV_F64 ? 1.0f / (16.0f * pk.wscale) : 1.0f;
+        a.unscale = (g.variant == CV_F64 || g.variant == CV_B1) ? 1.0f / ((g.variant == CV_B1 ? convb1_xscale() : CONVF_XSCALE) * pk.wscale) : 1.0f;
         a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.sel_kc_log2;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
@@ -778,12 +778,13 @@ static int finalize_weights(lns_engine* e, int device) {
     static const bool conv3_f16 = !(getenv("LNS_CONV3_SPLIT") && strcmp(getenv("LNS_CONV3_SPLIT"), "bf16x3") == 0);
     for (ConvPack& p : e->packs) {
         p.f16 = false; p.wscale = 1.0f;
-        if (!(p.has_wb && p.k == 3 && conv3_f16)) continue;
+        const bool want = p.has_wb && ((p.k == 3 && conv3_f16) || (p.k == 1 && convb1_xscale() != 1.0f));
+        if (!want) continue;
         float mx = 0.0f;
         for (const std::string& key : p.wkeys)
             for (float v : e->params[e->pindex.at(key)].host) mx = std::max(mx, fabsf(v));
-        if (!(mx > 0.0f) || !std::isfinite(mx)) continue;          // all-zero / non-finite weights: keep bf16x3
-        p.f16 = true;
+        if (!(mx > 0.0f) || !std::isfinite(mx)) { if (p.k == 1) p.wscale = 1.0f; continue; }   // all-zero weights: scale 1 (3x3: bf16x3)
+        p.f16 = p.k == 3;
         p.wscale = exp2f(floorf(log2f(16000.0f / mx)));
     }
     for (const ConvPack& p : e->packs) {
@@ -793,7 +794,7 @@ static int finalize_weights(lns_engine* e, int device) {
             pack_conv_weight(host.data() + p.w_off, w.host.data(), co, p.couts[i], p.cin, p.k, p.Cin_pad, p.Cout_pad);
             if (p.has_wb && p.k == 3 && !p.f16) convb_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
             if (p.has_wb && p.k == 3 && p.f16) convf_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad, p.wscale);
-            if (p.has_wb && p.k == 1) convb1_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
+            if (p.has_wb && p.k == 1) convb1_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad, p.wscale);
             if (!p.bkeys[i].empty()) {
                 const Param& b = e->params[e->pindex.at(p.bkeys[i])];
                 memcpy(host.data() + p.b_off + co, b.host.data(), (size_t)p.couts[i] * 4);
@@ -1465,9 +1466,9 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
     if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
     float wscale = 1.0f;
-    if (g.variant == CV_F64) {
+    if (g.variant == CV_F64 || (g.variant == CV_B1 && convb1_xscale() != 1.0f)) {
         float mx = 0.0f;
-        for (size_t i = 0; i < (size_t)Cout * Cin * 9; ++i) mx = std::max(mx, fabsf(w_host[i]));
+        for (size_t i = 0; i < (size_t)Cout * Cin * ksize * ksize; ++i) mx = std::max(mx, fabsf(w_host[i]));
         if (mx > 0.0f) wscale = exp2f(floorf(log2f(16000.0f / mx)));
     }
     const size_t wb_floats = (g.variant == CV_B64 || g.variant == CV_B32 || g.variant == CV_F64) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
@@ -1476,7 +1477,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
         hw.resize(hw.size() + wb_floats, 0.0f);
         if (g.variant == CV_F64) convf_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
         else if (g.variant != CV_B1) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
-        else convb1_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
+        else convb1_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
     }
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dw), hw.size() * 4));
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.dmaps), (rm.size() + cm.size()) * 4));
@@ -1493,7 +1494,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
-    a.unscale = g.variant == CV_F64 ? 1.0f / (16.0f * wscale) : 1.0f;
+    a.unscale = g.variant == CV_F64 ? 1.0f / (CONVF_XSCALE * wscale) : g.variant == CV_B1 ? 1.0f / (convb1_xscale() * wscale) : 1.0f;
     a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
     a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;

@@ -60,6 +60,10 @@ bool conv_fits(int variant, const ConvArgs& a);
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 // 3x3 convolution on bf16 MFMA with every fp32 operand split into three bf16 terms (6 products,
 // two accumulators): fp32-level accuracy at 2.7x the fp32-MFMA rate.  Tile 64 couts x 128 pixels.
+// f16x2 scheme: activations are multiplied by this power of two before the fp16 split.  Representable range
+// +-65504/32 = +-2047 (beyond: inf -> NaN results, loud); below 0.125/32 = 4e-3 the low term goes subnormal and the
+// absolute error per element is <= 2^-25/32 = 9e-10 (harmless unless a whole tensor is that small).
+#define CONVF_XSCALE 32.0f
 #define CONVB_SLAB_BYTES 27648           // one (cout tile, stage) weight slab: 3 splits x 9 taps x 64 couts x 8 ch bf16
 size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits);
 bool convb_fits(const ConvArgs& a);
@@ -72,7 +76,8 @@ void convf_pack_weight(void* dst, const float* w, int co0, int cout, int cin, in
 size_t convb1_lds_bytes(const ConvArgs& a);
 bool convb1_fits(const ConvArgs& a);
 size_t convb1_weight_bytes(int Cout, int Cin_pad);
-void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);
+void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale);
+float convb1_xscale();   // factor the 1x1 kernels apply to activations before the split (power of two; 1 for bf16x3)
 hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------

@@ -678,7 +678,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // SPL = 3: three bf16 terms, six products.  SPL = 2: two fp16 terms of the operand scaled by a power of two
-    // (activations x16 in the staging, weights per layer on the host), three products hh' + (hl' + lh'); the
+    // (activations x CONVF_XSCALE in the staging, weights per layer on the host), three products hh' + (hl' + lh'); the
     // dropped ll' term is <= 2^-24 |xy|.  Half the MFMAs and 2/3 of the LDS bytes at the accuracy of an fp32 chain.
     // MT = 1: 32-cout tiles (half a weight slab per block).  Same accumulation order, so the planner may pick it
     // freely; it is used when 64-cout tiles would leave CUs with fewer than two blocks.
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             if (sy >= 0 && sx >= 0) d = sy * a.Win + sx;
         }
         udm[u] = d >= 0 ? d : 0;
-        uok[u] = d >= 0 ? (SPL == 2 ? 16.0f : 1.0f) : 0.0f;     // fp16 split: activations are staged x16
+        uok[u] = d >= 0 ? (SPL == 2 ? CONVF_XSCALE : 1.0f) : 0.0f;     // fp16 split: activations are staged scaled
         uslot[u] = (p < PLANE ? p : PLANE) * 16;
     }
     // weight slab of this cout tile: host slabs hold 64 couts per (split, tap) row; a 32-cout block copies its half
@@ -948,11 +948,14 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 // A 1x1 conv has no tap reuse, so the fp32 -> 3 x bf16 split (VALU) is about as much work as the MFMAs;
 // it is interleaved with them the same way as in the 3x3 kernel.
 // ===========================================================================
-#define CONVB1_SLAB_BYTES 12288          // 3 splits x 4 octets x 64 couts x 8 ch bf16
+// split scheme of the 1x1 kernels: 2 = two fp16 terms of the scaled operand (f16x2, see the 3x3 kernel), 3 = three bf16 terms
+#define CONVB1_SPL 2
+#define CONVB1_XSCALE (CONVB1_SPL == 2 ? CONVF_XSCALE : 1.0f)
+#define CONVB1_SLAB_BYTES (CONVB1_SPL * 4 * 64 * 16)   // splits x 4 octets x 64 couts x 8 ch
 template <bool VEC2, bool FUSE2>
 __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
-    constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, NWU = 3;
-    constexpr int XB = 3 * 4 * TN * 16;                               // 24576
+    constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, SPL = CONVB1_SPL, NWU = CONVB1_SLAB_BYTES / 16 / 256;
+    constexpr int XB = SPL * 4 * TN * 16;
     constexpr int BUF = XB + CONVB1_SLAB_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds = smem;                                                  // 2 x [Xb | Wb]
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         uoct[u] = VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u;
         const bool pvalid = p0 + upx[u] < HW;
         udm[u] = pvalid ? p0 + upx[u] : 0;
-        uok[u] = pvalid ? 1.0f : 0.0f;
+        uok[u] = pvalid ? CONVB1_XSCALE : 0.0f;
     }
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)ct * (a.Cin_pad / KC) * CONVB1_SLAB_BYTES;
     const int aoff = (kh * TM + l31) * 16;                 // + (s*4 + 2j) * TM*16 + mt*32*16
@@ -1032,13 +1035,14 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
             if (MODE == 2) v = swish_fast(v);
             t[e] = v * uok[u];
         }
-        split3_pair(t[0], t[1], hq[u][cp], mq[u][cp], lq[u][cp]);
+        if (SPL == 3) split3_pair(t[0], t[1], hq[u][cp], mq[u][cp], lq[u][cp]);
+        else split2_pair_f16(t[0], t[1], hq[u][cp], mq[u][cp]);
     };
     auto flush_unit = [&](int u, char* Xn) __attribute__((always_inline)) {
         char* dst = Xn + (uoct[u] * TN + upx[u]) * 16;
         *reinterpret_cast<uint4*>(dst) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
         *reinterpret_cast<uint4*>(dst + 4 * TN * 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
-        *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
+        if (SPL == 3) *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
     };
     auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
         const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB1_SLAB_BYTES + (long)(tid + i * NTHR) * 16);
@@ -1047,14 +1051,14 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
     auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
         *reinterpret_cast<float4*>(Wn + (long)(tid + i * NTHR) * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
     };
-    auto load_frags = [&](int j, const char* Xs, const char* Ws, bf16x8 (&af)[3][MT], bf16x8 (&bf)[3])
+    auto load_frags = [&](int j, const char* Xs, const char* Ws, uint4 (&af)[SPL][MT], uint4 (&bf)[SPL])
                           __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < SPL; ++s) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                af[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + (s * 4 + 2 * j) * (TM * 16) + mt * (32 * 16) + aoff);
-            bf[s] = *reinterpret_cast<const bf16x8*>(Xs + (s * 4 + 2 * j) * (TN * 16) + boff);
+                af[s][mt] = *reinterpret_cast<const uint4*>(Ws + (s * 4 + 2 * j) * (TM * 16) + mt * (32 * 16) + aoff);
+            bf[s] = *reinterpret_cast<const uint4*>(Xs + (s * 4 + 2 * j) * (TN * 16) + boff);
         }
     };
 
@@ -1088,7 +1092,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
             char* Wn = Xn + XB;
             const int cw = c0 + KC < last ? c0 + KC : last;
             const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
-            bf16x8 af[2][3][MT], bf[2][3];
+            uint4 af[2][SPL][MT], bf[2][SPL];
             load_frags(0, Xs, Ws, af[0], bf[0]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -1097,13 +1101,22 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
                 auto& Bq = bf[j & 1];
 #define LNS_BX1(ACC, SA, SB)                                                                          \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
-        ACC[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA][mt], Bq[SB], ACC[mt][0], 0, 0, 0);
-                LNS_BX1(acc_lo, 1, 1)
-                LNS_BX1(acc_hi, 0, 0)
-                LNS_BX1(acc_lo, 0, 2)
-                LNS_BX1(acc_lo, 2, 0)
-                LNS_BX1(acc_lo, 0, 1)
-                LNS_BX1(acc_lo, 1, 0)
+        ACC[mt][0] = SPL == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA][mt]),              \
+                                    __builtin_bit_cast(bf16x8, Bq[SB]), ACC[mt][0], 0, 0, 0)                                  \
+                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA][mt]),                \
+                                    __builtin_bit_cast(f16x8, Bq[SB]), ACC[mt][0], 0, 0, 0);
+                if (SPL == 3) {
+                    LNS_BX1(acc_lo, 1, 1)
+                    LNS_BX1(acc_hi, 0, 0)
+                    LNS_BX1(acc_lo, 0, SPL - 1)
+                    LNS_BX1(acc_lo, SPL - 1, 0)
+                    LNS_BX1(acc_lo, 0, 1)
+                    LNS_BX1(acc_lo, 1, 0)
+                } else {
+                    LNS_BX1(acc_hi, 0, 0)
+                    LNS_BX1(acc_lo, 0, 1)
+                    LNS_BX1(acc_lo, 1, 0)
+                }
 #undef LNS_BX1
                 // k-step j stages channel pairs 2j, 2j+1 of both units and half of the weight slots
 #pragma unroll
@@ -1120,7 +1133,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
                 for (int i = 2 * j; i < 2 * j + 2; ++i)
                     if (i < NWU) { write_w(i, Wn); load_w(i, cl2); }
 #pragma unroll
-                for (int g = 0; g < 6 * MT; ++g) {
+                for (int g = 0; g < (SPL == 3 ? 6 : 3) * MT; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                     __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  // VALU
@@ -1151,8 +1164,8 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
 // streaming form (stage 0 then stage 1, k-steps in order), so either form gives the same bits.
 template <bool VEC2>
 __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
-    constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, NWU = 3;
-    constexpr int XB = 3 * 4 * TN * 16;
+    constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, SPL = CONVB1_SPL, NWU = CONVB1_SLAB_BYTES / 16 / 256;
+    constexpr int XB = SPL * 4 * TN * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xres = smem;                                                 // [stage 0..1][Xb]
     char* wbuf = smem + 2 * XB;                                        // [2][slab]
@@ -1185,7 +1198,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
             uoct[u] = VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u;
             const bool pvalid = p0 + upx[u] < HW;
             udm[u] = pvalid ? p0 + upx[u] : 0;
-            uok[u] = pvalid ? 1.0f : 0.0f;
+            uok[u] = pvalid ? CONVB1_XSCALE : 0.0f;
         }
         for (int st = 0; st < nstage; ++st) {
             float pv[NU][8];
@@ -1219,12 +1232,13 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
                         }
                         t[e] = v * uok[u];
                     }
-                    split3_pair(t[0], t[1], hq[cp], mq[cp], lq[cp]);
+                    if (SPL == 3) split3_pair(t[0], t[1], hq[cp], mq[cp], lq[cp]);
+                    else split2_pair_f16(t[0], t[1], hq[cp], mq[cp]);
                 }
                 char* dst = xres + st * XB + (uoct[u] * TN + upx[u]) * 16;
                 *reinterpret_cast<uint4*>(dst) = make_uint4(hq[0], hq[1], hq[2], hq[3]);
                 *reinterpret_cast<uint4*>(dst + 4 * TN * 16) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
-                *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+                if (SPL == 3) *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
             }
         }
     }
@@ -1268,14 +1282,14 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
         const char* Xs = xres + st * XB;
         const char* Ws = wbuf + (it & 1) * CONVB1_SLAB_BYTES;
         char* Wn = wbuf + ((it + 1) & 1) * CONVB1_SLAB_BYTES;
-        bf16x8 af[2][3][MT], bf[2][3];
-        auto load_frags = [&](int j, bf16x8 (&afj)[3][MT], bf16x8 (&bfj)[3]) __attribute__((always_inline)) {
+        uint4 af[2][SPL][MT], bf[2][SPL];
+        auto load_frags = [&](int j, uint4 (&afj)[SPL][MT], uint4 (&bfj)[SPL]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
+            for (int s = 0; s < SPL; ++s) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    afj[s][mt] = *reinterpret_cast<const bf16x8*>(Ws + (s * 4 + 2 * j) * (TM * 16) + mt * (32 * 16) + aoff);
-                bfj[s] = *reinterpret_cast<const bf16x8*>(Xs + (s * 4 + 2 * j) * (TN * 16) + boff);
+                    afj[s][mt] = *reinterpret_cast<const uint4*>(Ws + (s * 4 + 2 * j) * (TM * 16) + mt * (32 * 16) + aoff);
+                bfj[s] = *reinterpret_cast<const uint4*>(Xs + (s * 4 + 2 * j) * (TN * 16) + boff);
             }
         };
         load_frags(0, af[0], bf[0]);
@@ -1286,19 +1300,28 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
             auto& Bq = bf[j & 1];
 #define LNS_BX1(ACC, SA, SB)                                                                          \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
-        ACC[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA][mt], Bq[SB], ACC[mt][0], 0, 0, 0);
-            LNS_BX1(acc_lo, 1, 1)
-            LNS_BX1(acc_hi, 0, 0)
-            LNS_BX1(acc_lo, 0, 2)
-            LNS_BX1(acc_lo, 2, 0)
-            LNS_BX1(acc_lo, 0, 1)
-            LNS_BX1(acc_lo, 1, 0)
+        ACC[mt][0] = SPL == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA][mt]),              \
+                                    __builtin_bit_cast(bf16x8, Bq[SB]), ACC[mt][0], 0, 0, 0)                                  \
+                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA][mt]),                \
+                                    __builtin_bit_cast(f16x8, Bq[SB]), ACC[mt][0], 0, 0, 0);
+            if (SPL == 3) {
+                LNS_BX1(acc_lo, 1, 1)
+                LNS_BX1(acc_hi, 0, 0)
+                LNS_BX1(acc_lo, 0, SPL - 1)
+                LNS_BX1(acc_lo, SPL - 1, 0)
+                LNS_BX1(acc_lo, 0, 1)
+                LNS_BX1(acc_lo, 1, 0)
+            } else {
+                LNS_BX1(acc_hi, 0, 0)
+                LNS_BX1(acc_lo, 0, 1)
+                LNS_BX1(acc_lo, 1, 0)
+            }
 #undef LNS_BX1
 #pragma unroll
             for (int i = 2 * j; i < 2 * j + 2; ++i)
                 if (i < NWU) { write_w(i, Wn); load_w(i, it + 2); }
 #pragma unroll
-            for (int g = 0; g < 6 * MT; ++g) {
+            for (int g = 0; g < (SPL == 3 ? 6 : 3) * MT; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
@@ -1316,7 +1339,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
     }
 }
 
-size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (3 * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 16; }
+size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 16; }
 
 bool convb1_fits(const ConvArgs& a) {
     return a.ks == 1 && a.stride == 1 && (a.Cin_pad % 32) == 0 && a.wb != nullptr && convb1_lds_bytes(a) <= 150 * 1024;
@@ -1450,7 +1473,29 @@ void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, in
     }
 }
 
-void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad) {
+float convb1_xscale() { return CONVB1_XSCALE; }
+
+void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale) {
+    if (CONVB1_SPL == 2) {
+        uint16_t* d = static_cast<uint16_t*>(dst);
+        const int nstage = Cin_pad / 32;
+        for (int co = 0; co < cout; ++co) {
+            const int cog = co0 + co, ct = cog / 64, cl = cog % 64;
+            for (int ci = 0; ci < cin; ++ci) {
+                const int st = ci / 32, oct = (ci % 32) / 8, c = ci % 8;
+                const float v = w[(size_t)co * cin + ci] * wscale;
+                float hb, lb;
+                uint16_t q[2];
+                q[0] = host_f16_rne(v, &hb);
+                q[1] = host_f16_rne(v - hb, &lb);
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const size_t unit = (((size_t)ct * nstage + st) * 2 + sidx) * 4 + oct;
+                    d[(unit * 64 + cl) * 8 + c] = q[sidx];
+                }
+            }
+        }
+        return;
+    }
     uint16_t* d = static_cast<uint16_t*>(dst);
     const int nstage = Cin_pad / 32;
     for (int co = 0; co < cout; ++co) {

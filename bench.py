@@ -27,10 +27,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
-BF16_MFMA_PEAK_TFLOPS = 2516.6      # MI355X dense bf16 matrix peak = 16 x the fp32 matrix rate (same guide)
-# The 3x3 convolution runs on the bf16 pipe with every fp32 operand split into three bf16 terms: six bf16
-# products per fp32 product and 10 tap slots for 9 taps = 6.67 executed bf16 FLOP per algorithmic FLOP.
-BF16X3_EXEC_PER_ALGO = 6.0 * 10.0 / 9.0
+F16_MFMA_PEAK_TFLOPS = 2516.6       # MI355X dense fp16/bf16 matrix peak = 16 x the fp32 matrix rate (same guide)
+# The 3x3 convolution runs on the 16-bit matrix pipe with every (scaled) fp32 operand split into two fp16 terms:
+# three fp16 products per fp32 product and 10 tap slots for 9 taps = 3.33 executed fp16 FLOP per algorithmic FLOP.
+SPLIT_EXEC_PER_ALGO = 3.0 * 10.0 / 9.0
 FLOP_PER_TRAJ_STEP = 5.926e9        # 0.732 propagate + 5.194 decode
 FLOP_ENCODE = 5.385e9
 
@@ -204,14 +204,14 @@ def main():
         k = tm.get("conv3x3_mfma")
         if k:
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
-            peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_EXEC_PER_ALGO
+            peak = F16_MFMA_PEAK_TFLOPS / SPLIT_EXEC_PER_ALGO
             result["roofline"] = {
-                "kernel": "conv3_bf16x3_kernel (3x3 implicit GEMM; fp32 operands as 3 bf16 terms on bf16 MFMA, fp32 accumulate)",
+                "kernel": "conv3_bf16x3_kernel<..., SPL=2> (3x3 implicit GEMM; fp32 operands as 2 fp16 terms on v_mfma_f32_32x32x16_f16, fp32 accumulate)",
                 "bound": "mfma",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "peak_basis": "algorithmic fp32 FLOP: dense bf16 MFMA peak %.1f / %.2f executed bf16 FLOP per algorithmic FLOP"
-                              % (BF16_MFMA_PEAK_TFLOPS, BF16X3_EXEC_PER_ALGO),
-                "executed_bf16_tflops": ach * BF16X3_EXEC_PER_ALGO,
+                "peak_basis": "algorithmic fp32 FLOP: dense fp16 MFMA peak %.1f / %.2f executed fp16 FLOP per algorithmic FLOP"
+                              % (F16_MFMA_PEAK_TFLOPS, SPLIT_EXEC_PER_ALGO),
+                "executed_f16_tflops": ach * SPLIT_EXEC_PER_ALGO,
                 "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                 "traffic": traffic_from_profiles("conv3x3"), "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
                 "algorithmic_flop_per_launch": k["flops"] / k["launches"],

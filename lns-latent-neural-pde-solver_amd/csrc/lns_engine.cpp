@@ -100,7 +100,7 @@ struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Ho
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
                           int kc_log2_pack, int Cout_pad, int force_variant, bool need_wgm1 = false,
-                          bool allow_bf16x3 = false, int Cin = 1 << 30, bool f16x2 = false) {
+                          bool allow_bf16x3 = false, int Cin = 1 << 30, bool f16x2 = false, bool allow_thin = false) {
     g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
     g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
     if (g.Hout <= 0 || g.Wout <= 0) return false;
@@ -123,6 +123,10 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
     // bandwidth-bound, and a 64-cout MFMA tile would be mostly padding) -- again a per-layer rule
     if (force_variant < 0 && allow_bf16x3 && !no_bf16x3 && !no_b1 && k == 1 && stride == 1 && Cout > 32 && Cin >= 16)
         cands = {(int)CV_B1};
+    // <= 4 output channels (the decoder's last conv): streaming VALU kernel, one HBM read of the input
+    static const bool no_thin = getenv("LNS_CONV1_NO_THIN") != nullptr;
+    if (force_variant < 0 && allow_thin && !no_thin && k == 1 && stride == 1 && Cout <= 4 && Cin <= 512 && (Hv * Wv) % 4 == 0)
+        cands = {(int)CV_THIN};
     g.kc_log2 = conv_pick_kc_log2(k, stride, kc_log2_pack);
     static const int pref[] = {5, 6, 4, 7, 3, 8};   // log2 BW preference on ties: 32,64,16,128,8,256
     bool found = false;
@@ -179,7 +183,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
             static const long want = getenv("LNS_CONVB32_BELOW") ? atol(getenv("LNS_CONVB32_BELOW")) : 0;
             if (blocks < want) { g.variant = CV_B32; g.cout_tiles = (Cout + 31) / 32; }
         }
-        if (cands[ci] >= CV_B64) break;                        // never fall through to fp32 by launch size
+        if (cands[ci] >= CV_B64) break;                        // never fall through to another kernel family by launch size
         if (blocks >= min_blocks) break;
     }
     return found;
@@ -326,7 +330,10 @@ struct Planner {
         if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
         const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
         ConvGeom g;
-        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb, pk.cin, pk.f16))
+        const bool thin_ok = !res && !badd && act_out == ACT_NONE && fuse_pack < 0 && !in.vH &&
+                             (in.act == ACT_NONE || (in.act == ACT_SWISH && in.ss != 0));
+        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb, pk.cin, pk.f16,
+                           thin_ok))
             throw std::runtime_error("no conv tiling for " + name);
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;

@@ -51,7 +51,8 @@ struct ConvArgs {
 enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4, CV_S32 = 5, CV_COUNT = 6,
                    CV_B64 = 6 /* bf16x3 3x3 kernel */, CV_B1 = 7 /* bf16x3 1x1 kernel */,          // both 64 couts x 128 pixels
                    CV_B32 = 9 /* bf16x3 3x3 kernel, 32 couts x 128 pixels (same bits as CV_B64) */,
-                   CV_F64 = 11 /* 3x3 kernel with the two-term fp16 split (f16x2), 64 couts x 128 pixels */ };
+                   CV_F64 = 11 /* 3x3 kernel with the two-term fp16 split (f16x2), 64 couts x 128 pixels */,
+                   CV_THIN = 12 /* streaming 1x1 projection to <= 4 output channels (VALU, HBM-bound) */ };
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
 size_t conv_lds_bytes(int variant, const ConvArgs& a);
@@ -79,6 +80,8 @@ size_t convb1_weight_bytes(int Cout, int Cin_pad);
 void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale);
 float convb1_xscale();   // factor the 1x1 kernels apply to activations before the split (power of two; 1 for bf16x3)
 hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s);
+bool conv1_thin_fits(const ConvArgs& a);
+hipError_t launch_conv1_thin(const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // GroupNorm statistics -> per-(b,c) scale/shift (fused into the consumer conv)

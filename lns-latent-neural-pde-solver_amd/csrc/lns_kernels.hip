@@ -449,7 +449,8 @@ static const ConvVariantInfo kConvInfo[CV_COUNT] = {
     {128, 256}, {64, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 128}};
 
 ConvVariantInfo conv_variant_info(int v) {
-    return v == CV_B32 ? ConvVariantInfo{32, 128} : v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v];
+    return v == CV_B32 ? ConvVariantInfo{32, 128} : v == CV_THIN ? ConvVariantInfo{32, 1024}
+           : v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v];
 }
 
 // Stage depth (channels per LDS stage).  It is a function of the kernel size ONLY
@@ -468,6 +469,7 @@ static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
     if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return convb_lds_bytes(a, variant == CV_B32 ? 32 : 64, variant == CV_F64 ? 2 : 3);
     if (variant == CV_B1) return convb1_lds_bytes(a);
+    if (variant == CV_THIN) return 0;
     const int KC = 1 << a.kc_log2;
     const int TM = kConvInfo[variant].TM;
     const size_t xs = (size_t)conv_maxe(a.ks, KC) * 256;
@@ -478,6 +480,7 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 bool conv_fits(int variant, const ConvArgs& a) {
     if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return convb_fits(a);
     if (variant == CV_B1) return convb1_fits(a);
+    if (variant == CV_THIN) return a.ks == 1 && a.stride == 1;   // pointer-dependent conditions are checked at launch
     const long KC = 1 << a.kc_log2;
     const int TN = kConvInfo[variant].TN;
     if (a.ks == 3 ? (KC != 4 && KC != 8) : (KC != 16)) return false;
@@ -511,6 +514,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
     if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return launch_conv_bf16x3(variant, a, s);
     if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
+    if (variant == CV_THIN) return launch_conv1_thin(a, s);
     if (!conv_fits(variant, a)) return hipErrorInvalidValue;
     const size_t lds = conv_lds_bytes(variant, a);
     switch (variant) {
@@ -1546,6 +1550,84 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
         if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false>), grid, dim3(256), lds, s, a);
     }
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// Thin 1x1 projection (<= 4 output channels, e.g. the decoder's last 64 -> 3 conv): pure streaming, no matrix pipe.
+// A thread owns 4 consecutive pixels and walks the input channels with 16-byte loads (8 in flight), applying the
+// GroupNorm scale/shift + Swish prologue and accumulating the <= 4 outputs with fp32 FMAs in channel order.
+// HBM-bound: one read of the input.
+// ===========================================================================
+__global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
+    __shared__ float wsm[4 * 512];          // [co][c]
+    __shared__ float2 ssm[512];             // (scale, shift) per channel
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int HW = a.Hin * a.Win, C = a.Cin, CO = a.Cout;
+    const bool has_ss = a.ss != nullptr;
+    for (int i = tid; i < CO * C; i += 256) {                     // fp32 pack [tap 1][Cin_pad][Cout_pad]
+        const int co = i / C, c = i - co * C;
+        wsm[co * 512 + c] = a.w[(long)c * a.Cout_pad + co];
+    }
+    for (int i = tid; i < C; i += 256)
+        ssm[i] = has_ss ? make_float2(a.ss[((long)b * C + i) * 2], a.ss[((long)b * C + i) * 2 + 1]) : make_float2(1.0f, 0.0f);
+    __syncthreads();
+    const int p4 = blockIdx.x * 256 + tid;                        // group of 4 pixels
+    if (p4 * 4 >= HW) return;
+    const float* xb = a.x + (long)b * a.x_bs + (long)p4 * 4;
+    const bool swish = has_ss && a.act_in == ACT_SWISH;
+    float acc[4][4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[co][e] = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u < C ? c0 + u : C - 1;
+            v[u] = *reinterpret_cast<const float4*>(xb + (long)c * HW);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + u < C) {
+                const float2 st = ssm[c0 + u];
+                float t[4] = {v[u].x * st.x + st.y, v[u].y * st.x + st.y, v[u].z * st.x + st.y, v[u].w * st.x + st.y};
+                if (swish) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = swish_fast(t[e]);
+                }
+#pragma unroll
+                for (int co = 0; co < 4; ++co) {
+                    if (co < CO) {
+                        const float wv = wsm[co * 512 + c0 + u];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[co][e] = fmaf(wv, t[e], acc[co][e]);
+                    }
+                }
+            }
+        }
+    }
+    float* yb = a.y + (long)b * a.y_bs + (long)p4 * 4;
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        if (co < CO) {
+            const float bv = a.bias ? a.bias[co] : 0.0f;
+            *reinterpret_cast<float4*>(yb + (long)co * HW) = make_float4(acc[co][0] + bv, acc[co][1] + bv, acc[co][2] + bv, acc[co][3] + bv);
+        }
+    }
+}
+
+bool conv1_thin_fits(const ConvArgs& a) {
+    return a.ks == 1 && a.stride == 1 && a.Cout <= 4 && a.Cin <= 512 && ((a.Hin * a.Win) % 4) == 0 && !a.res && !a.badd &&
+           a.act_out == ACT_NONE && !a.w2 && (a.act_in == ACT_NONE || a.act_in == ACT_SWISH) && (a.x_bs % 4) == 0 &&
+           (a.y_bs % 4) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y)) & 15) == 0;
+}
+
+hipError_t launch_conv1_thin(const ConvArgs& a, hipStream_t s) {
+    if (!conv1_thin_fits(a)) return hipErrorInvalidValue;
+    const int groups = a.Hin * a.Win / 4;
+    hipLaunchKernelGGL(conv1_thin_kernel, dim3((groups + 255) / 256, a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -132,6 +132,10 @@ for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, C
            dict(B=3, Cin=64, Cout=2048, H=1, W=64, bias=False), dict(B=2, Cin=40, Cout=72, H=7, W=15, ss=True, badd=True),
            dict(B=1, Cin=96, Cout=96, H=20, W=36, ss=True, act_in=1, act_out=2)]:
     CONV_CASES.append(dict(k=1, variant=7, **_c))
+# thin streaming projection (variant 12): <= 4 output channels
+for _c in [dict(B=2, Cin=64, Cout=3, H=64, W=64, ss=True, act_in=1), dict(B=3, Cin=16, Cout=1, H=8, W=12),
+           dict(B=2, Cin=37, Cout=4, H=20, W=36, ss=True, bias=False), dict(B=1, Cin=128, Cout=2, H=32, W=32, ss=True, act_in=1)]:
+    CONV_CASES.append(dict(k=1, variant=12, **_c))
 # the same kernel in its input-stationary form (variant code 8: blocks walk over 3 cout tiles, ragged last chunk)
 for _c in [dict(B=2, Cin=64, Cout=512, H=32, W=32, ss=True, bias=False), dict(B=2, Cin=16, Cout=128, H=16, W=16),
            dict(B=2, Cin=40, Cout=200, H=7, W=15, ss=True, act_in=1, act_out=2, badd=True),

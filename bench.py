@@ -227,7 +227,7 @@ def main():
                                         "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                                     for n, v in sorted(tm.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, sd, 4, 8)
+        result["cpu_baseline"] = cpu_baseline(args, sd, 8, 32)
         result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))

@@ -390,6 +390,12 @@ struct Planner {
             a.w2 = as_ptr<const float>(wt(p2.w_off));
             a.bias2 = p2.has_bias ? as_ptr<const float>(wt(p2.b_off)) : nullptr;
             a.Cout2_pad = p2.Cout_pad;
+            {   // scale of the fused 1x1 weights for the fp16 split in the epilogue (max |w2| just below 2^14)
+                float mx = 0.0f;
+                for (const std::string& key : p2.wkeys)
+                    for (float v : e->params[e->pindex.at(key)].host) mx = std::max(mx, fabsf(v));
+                a.w2scale = (mx > 0.0f && std::isfinite(mx)) ? exp2f(floorf(log2f(16000.0f / mx))) : 1.0f;
+            }
             op.flops += 2.0 * B * g.Hout * g.Wout * 64.0 * 64.0;
         }
         plan->ops.push_back(op);

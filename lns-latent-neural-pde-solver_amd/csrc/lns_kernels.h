@@ -39,6 +39,7 @@ struct ConvArgs {
     // optional fused second 1x1 conv (Cout -> Cout, Cout == tile height 64): applied after act_out,
     // before the residual add.  w2: packed [Cout][Cout2_pad] slab of the 1x1 weight, bias2 [Cout].
     const float* w2; const float* bias2; int Cout2_pad;
+    float w2scale;         // split-operand kernels: power-of-two scale applied to w2 before its fp16 split
     // bf16x3 path (3x3, stride 1): weights pre-split into 3 bf16 terms,
     // layout [cout tile][stage of 8 ch][split 3][tap 9][64 cout][8 ch]
     const void* wb;

@@ -629,33 +629,67 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
     }
     if (FUSE2) {
-        float* W2s = reinterpret_cast<float*>(lds);
+        // Second 1x1 conv (64 -> 64) on the same split-operand scheme: the accumulator tile Y1 (channels in
+        // registers, pixels on lanes) is scaled, split into two fp16 terms IN REGISTERS and is the B operand
+        // (k-step t' of channel block mt takes accumulator registers 8t'..8t'+7, i.e. channels
+        // mt*32 + 16t' + 4kh + {0..3, 8..11}); W2 is scaled, split and stored in LDS with its input channels
+        // permuted inside every 16-block so that those 8 channels are 8 consecutive k positions of the A operand.
+        constexpr int W2W = TM + 8;                               // row stride in fp16 elements (16-byte aligned rows)
+        unsigned short* W2s = reinterpret_cast<unsigned short*>(lds);   // [2][co2][W2W]
         __syncthreads();
-        for (int i = tid; i < TM * TM / 4; i += NTHR) {
-            const int k = i / (TM / 4), c4 = i - k * (TM / 4);
-            *reinterpret_cast<float4*>(W2s + k * TM + c4 * 4) =
-                *reinterpret_cast<const float4*>(a.w2 + (long)k * a.Cout2_pad + c4 * 4);
+        {
+            float v[TM * TM / NTHR];
+#pragma unroll
+            for (int u = 0; u < TM * TM / NTHR; ++u) {
+                const int i = tid + u * NTHR, k = i / TM, co2 = i - k * TM;      // fp32 pack [k = co1][Cout2_pad]
+                v[u] = a.w2[(long)k * a.Cout2_pad + co2] * a.w2scale;
+            }
+#pragma unroll
+            for (int u = 0; u < TM * TM / NTHR; ++u) {
+                const int i = tid + u * NTHR, k = i / TM, co2 = i - k * TM;
+                const int w = k & 15;
+                const int kp = (k & ~15) | (w & 3) | (((w >> 3) & 1) << 2) | (((w >> 2) & 1) << 3);
+                const _Float16 hh = (_Float16)v[u];
+                const _Float16 ll = (_Float16)(v[u] - (float)hh);
+                W2s[(0 * TM + co2) * W2W + kp] = __builtin_bit_cast(unsigned short, hh);
+                W2s[(1 * TM + co2) * W2W + kp] = __builtin_bit_cast(unsigned short, ll);
+            }
         }
         __syncthreads();
+        const float unscale2 = 1.0f / (CONVF_XSCALE * a.w2scale);
+        const char* w2a = reinterpret_cast<const char*>(W2s) + (l31 * W2W + 8 * kh) * 2;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f32x16 acc2[MT];
+            f32x16 a2h[MT], a2l[MT];
 #pragma unroll
-            for (int m2 = 0; m2 < MT; ++m2) {
+            for (int m2 = 0; m2 < MT; ++m2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[m2][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) { a2h[m2][r] = 0.0f; a2l[m2][r] = 0.0f; }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc2[m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            W2s[(mt * 32 + drow(r, kh)) * TM + m2 * 32 + l31], acc[mt][nt][r], acc2[m2], 0, 0, 0);
-            }
+                for (int tp = 0; tp < 2; ++tp) {
+                    unsigned hq[4], lq[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        split2_pair_f16(acc[mt][nt][8 * tp + 2 * e] * CONVF_XSCALE, acc[mt][nt][8 * tp + 2 * e + 1] * CONVF_XSCALE, hq[e], lq[e]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(hq[0], hq[1], hq[2], hq[3]));
+                    const f16x8 bl = __builtin_bit_cast(f16x8, make_uint4(lq[0], lq[1], lq[2], lq[3]));
+#pragma unroll
+                    for (int m2 = 0; m2 < MT; ++m2) {
+                        const char* wp = w2a + (m2 * 32) * (W2W * 2) + (mt * 32 + 16 * tp) * 2;
+                        const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
+                        const f16x8 al = *reinterpret_cast<const f16x8*>(wp + TM * W2W * 2);
+                        a2h[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a2h[m2], 0, 0, 0);
+                        a2l[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a2l[m2], 0, 0, 0);
+                        a2l[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a2l[m2], 0, 0, 0);
+                    }
+                }
 #pragma unroll
             for (int m2 = 0; m2 < MT; ++m2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[m2][nt][r] = acc2[m2][r] + (a.bias2 ? a.bias2[m2 * 32 + drow(r, kh)] : 0.0f);
+                    acc[m2][nt][r] = (a2h[m2][r] + a2l[m2][r]) * unscale2 + (a.bias2 ? a.bias2[m2 * 32 + drow(r, kh)] : 0.0f);
         }
     }
 #pragma unroll

@@ -930,6 +930,14 @@ struct Runner {
                 HIPCHK(e, hipEventRecord(ev.a, stream));
             }
             hipError_t rc = hipSuccess;
+            // diagnostic (timing what-ifs only, results are garbage): LNS_SKIP_OPS=gn,fasmall
+            static const char* skip = getenv("LNS_SKIP_OPS");
+            if (skip) {
+                const bool is_gn = op.type == OP_GNSTATS;
+                const bool is_fas = op.type == OP_FAPOOL || op.type == OP_FARED || op.type == OP_FALRK ||
+                                    (op.type == OP_CONV && op.name.find("to_qk") != std::string::npos);
+                if ((is_gn && strstr(skip, "gn")) || (is_fas && strstr(skip, "fasmall"))) continue;
+            }
             switch (op.type) {
                 case OP_CONV: {
                     ConvArgs a = op.conv;

@@ -63,9 +63,10 @@ hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 // 3x3 convolution on bf16 MFMA with every fp32 operand split into three bf16 terms (6 products,
 // two accumulators): fp32-level accuracy at 2.7x the fp32-MFMA rate.  Tile 64 couts x 128 pixels.
 // f16x2 scheme: activations are multiplied by this power of two before the fp16 split.  Representable range
-// +-65504/32 = +-2047 (beyond: inf -> NaN results, loud); below 0.125/32 = 4e-3 the low term goes subnormal and the
-// absolute error per element is <= 2^-25/32 = 9e-10 (harmless unless a whole tensor is that small).
-#define CONVF_XSCALE 32.0f
+// +-65504/16 = +-4094 (beyond: inf -> NaN results, loud); below 0.125/16 = 8e-3 the low term goes subnormal and the
+// absolute error per element is <= 2^-25/16 = 1.9e-9 (harmless unless a whole tensor is that small: a tensor of
+// N(0, 1e-3^2) values convolves with 1.1e-6 relative error instead of 1.7e-7).
+#define CONVF_XSCALE 16.0f
 #define CONVB_SLAB_BYTES 27648           // one (cout tile, stage) weight slab: 3 splits x 9 taps x 64 couts x 8 ch bf16
 size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits);
 bool convb_fits(const ConvArgs& a);

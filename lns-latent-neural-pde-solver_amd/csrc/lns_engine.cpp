@@ -503,36 +503,68 @@ struct Planner {
             plan->ops.push_back(op);
         }
         free_t(v);
-        TRef ux = alloc_t(lat, 1, H), uy = alloc_t(lat, 1, W);
-        for (int ax = 0; ax < 2; ++ax) {
+        // PoolingReducer of both axes in ONE launch, rotary + q k^T of both axes in one more
+        // (LNS_FA_NO_MERGE restores one launch per axis)
+        static const bool no_merge = getenv("LNS_FA_NO_MERGE") != nullptr;
+        const bool merge = !no_merge && C % 32 == 0 && C <= 256;
+        auto fill_reducer = [&](FaReducerArgs& fr, int ax) {
             const int* r = ax == 0 ? l.rx : l.ry;
             const int n = ax == 0 ? H : W;
-            Op op;
-            op.type = OP_FARED; op.name = l.name + (ax == 0 ? ".to_x" : ".to_y"); op.cls = CLS_FARED;
-            memset(&op.fr, 0, sizeof op.fr);
-            op.fr.m = as_ptr<const float>(tag(SP_WS, ax == 0 ? mx_off : my_off));
-            op.fr.rows = (long)B * n; op.fr.n = n; op.fr.C = C; op.fr.Hid = 2 * C; op.fr.Out = lat;
-            op.fr.win_t = as_ptr<const float>(vecp(r[0])); op.fr.ln_g = as_ptr<const float>(vecp(r[1]));
-            op.fr.ln_b = as_ptr<const float>(vecp(r[2])); op.fr.w1_t = as_ptr<const float>(vecp(r[3]));
-            op.fr.w2_t = as_ptr<const float>(vecp(r[4])); op.fr.b2 = as_ptr<const float>(vecp(r[5]));
-            op.fr.u = as_ptr<float>((ax == 0 ? ux : uy).ptr);
-            op.flops = 2.0 * B * n * ((double)C * C + 2.0 * C * C + 2.0 * C * lat);
-            plan->ops.push_back(op);
+            memset(&fr, 0, sizeof fr);
+            fr.m = as_ptr<const float>(tag(SP_WS, ax == 0 ? mx_off : my_off));
+            fr.rows = (long)B * n; fr.n = n; fr.C = C; fr.Hid = 2 * C; fr.Out = lat;
+            fr.win_t = as_ptr<const float>(vecp(r[0])); fr.ln_g = as_ptr<const float>(vecp(r[1]));
+            fr.ln_b = as_ptr<const float>(vecp(r[2])); fr.w1_t = as_ptr<const float>(vecp(r[3]));
+            fr.w2_t = as_ptr<const float>(vecp(r[4])); fr.b2 = as_ptr<const float>(vecp(r[5]));
+        };
+        // (fusing to_qk into the reducer as a fourth chained GEMM was measured slower: 163 us per launch against
+        //  2 x 25 us for the stand-alone convolutions, the projection has too little parallelism per 32-row block)
+        TRef qkx, qky;
+        {
+            TRef ux = alloc_t(lat, 1, H), uy = alloc_t(lat, 1, W);
+            if (merge) {
+                Op op;
+                op.type = OP_FARED2; op.name = l.name + ".to_xy"; op.cls = CLS_FARED;
+                fill_reducer(op.fr, 0); fill_reducer(op.fr2, 1);
+                op.fr.u = as_ptr<float>(ux.ptr); op.fr2.u = as_ptr<float>(uy.ptr);
+                op.flops = 2.0 * B * (H + W) * ((double)C * C + 2.0 * C * C + 2.0 * C * lat);
+                plan->ops.push_back(op);
+            } else {
+                for (int ax = 0; ax < 2; ++ax) {
+                    Op op;
+                    op.type = OP_FARED; op.name = l.name + (ax == 0 ? ".to_x" : ".to_y"); op.cls = CLS_FARED;
+                    fill_reducer(op.fr, ax);
+                    op.fr.u = as_ptr<float>((ax == 0 ? ux : uy).ptr);
+                    op.flops = 2.0 * B * (ax == 0 ? H : W) * ((double)C * C + 2.0 * C * C + 2.0 * C * lat);
+                    plan->ops.push_back(op);
+                }
+            }
+            arena.release(mx_off); arena.release(my_off);
+            qkx = conv_same1(ux, l.qkx, ACT_NONE, nullptr, nullptr, l.name + ".lrk_x.to_qk");
+            qky = conv_same1(uy, l.qky, ACT_NONE, nullptr, nullptr, l.name + ".lrk_y.to_qk");
+            free_t(ux); free_t(uy);
         }
-        arena.release(mx_off); arena.release(my_off);
-        TRef qkx = conv_same1(ux, l.qkx, ACT_NONE, nullptr, nullptr, l.name + ".lrk_x.to_qk");
-        TRef qky = conv_same1(uy, l.qky, ACT_NONE, nullptr, nullptr, l.name + ".lrk_y.to_qk");
-        free_t(ux); free_t(uy);
         const size_t kx_off = arena.alloc((size_t)B * heads * H * H * 4), ky_off = arena.alloc((size_t)B * heads * W * W * 4);
-        for (int ax = 0; ax < 2; ++ax) {
-            const int n = ax == 0 ? H : W;
+        {
             Op op;
-            op.type = OP_FALRK; op.name = l.name + (ax == 0 ? ".lrk_x" : ".lrk_y"); op.cls = CLS_FALRK;
-            op.fl.qk = as_ptr<const float>((ax == 0 ? qkx : qky).ptr); op.fl.B = B; op.fl.heads = heads; op.fl.DK = DK;
-            op.fl.n = n; op.fl.cs = as_ptr<const float>(rotary_table(n, ax == 0 ? l.invf_x : l.invf_y));
-            op.fl.kmat = as_ptr<float>(tag(SP_WS, ax == 0 ? kx_off : ky_off));
-            op.flops = 2.0 * B * heads * (double)n * n * DK;
-            plan->ops.push_back(op);
+            op.type = merge ? OP_FALRK2 : OP_FALRK; op.cls = CLS_FALRK;
+            for (int ax = 0; ax < 2; ++ax) {
+                const int n = ax == 0 ? H : W;
+                FaLrkArgs& fl = (merge && ax == 1) ? op.fl2 : op.fl;
+                fl.qk = as_ptr<const float>((ax == 0 ? qkx : qky).ptr); fl.B = B; fl.heads = heads; fl.DK = DK;
+                fl.n = n; fl.cs = as_ptr<const float>(rotary_table(n, ax == 0 ? l.invf_x : l.invf_y));
+                fl.kmat = as_ptr<float>(tag(SP_WS, ax == 0 ? kx_off : ky_off));
+                if (!merge) {
+                    op.name = l.name + (ax == 0 ? ".lrk_x" : ".lrk_y");
+                    op.flops = 2.0 * B * heads * (double)n * n * DK;
+                    plan->ops.push_back(op);
+                }
+            }
+            if (merge) {
+                op.name = l.name + ".lrk_xy";
+                op.flops = 2.0 * B * heads * ((double)H * H + (double)W * W) * DK;
+                plan->ops.push_back(op);
+            }
         }
         free_t(qkx); free_t(qky);
         {
@@ -761,7 +793,8 @@ struct Planner {
                 p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(tag(SP_CT, off));
             };
             if (op.type == OP_CONV) { rebase(op.conv.rowmap); rebase(op.conv.colmap); }
-            if (op.type == OP_FALRK) rebase(op.fl.cs);
+            if (op.type == OP_FALRK || op.type == OP_FALRK2) rebase(op.fl.cs);
+            if (op.type == OP_FALRK2) rebase(op.fl2.cs);
             if (op.type == OP_CONDBASE) rebase(op.cb.freqs);
         }
         plan->arena_bytes = arena.high;
@@ -934,7 +967,7 @@ struct Runner {
             static const char* skip = getenv("LNS_SKIP_OPS");
             if (skip) {
                 const bool is_gn = op.type == OP_GNSTATS;
-                const bool is_fas = op.type == OP_FAPOOL || op.type == OP_FARED || op.type == OP_FALRK ||
+                const bool is_fas = op.type == OP_FAPOOL || op.type == OP_FARED || op.type == OP_FALRK || op.type == OP_FARED2 || op.type == OP_FALRK2 ||
                                     (op.type == OP_CONV && op.name.find("to_qk") != std::string::npos);
                 if ((is_gn && strstr(skip, "gn")) || (is_fas && strstr(skip, "fasmall"))) continue;
             }
@@ -968,7 +1001,22 @@ struct Runner {
                     rc = launch_fa_reducer(a, stream);
                     break;
                 }
+                case OP_FARED2: {
+                    FaReducerArgs a[2] = {op.fr, op.fr2};
+                    for (int i = 0; i < 2; ++i) {
+                        fix(a[i].m, B); fix(a[i].win_t, B); fix(a[i].ln_g, B); fix(a[i].ln_b, B); fix(a[i].w1_t, B); fix(a[i].w2_t, B);
+                        fix(a[i].b2, B); fix(a[i].u, B); fix(a[i].wqk_t, B); fix(a[i].bqk, B); fix(a[i].qk, B);
+                    }
+                    rc = launch_fa_reducer2(a[0], a[1], stream);
+                    break;
+                }
                 case OP_FALRK: { FaLrkArgs a = op.fl; fix(a.qk, B); fix(a.cs, B); fix(a.kmat, B); rc = launch_fa_lrk(a, stream); break; }
+                case OP_FALRK2: {
+                    FaLrkArgs a[2] = {op.fl, op.fl2};
+                    for (int i = 0; i < 2; ++i) { fix(a[i].qk, B); fix(a[i].cs, B); fix(a[i].kmat, B); }
+                    rc = launch_fa_lrk2(a[0], a[1], stream);
+                    break;
+                }
                 case OP_FASAND: {
                     FaSandwichArgs a = op.fs;
                     fix(a.u, B); fix(a.kx, B); fix(a.ky, B); fix(a.out, B);

@@ -70,7 +70,7 @@ struct Layer {
 enum Space { SP_NULL = 0, SP_WS = 1, SP_WT = 2, SP_CT = 3, SP_EXT0 = 4 };   // ext slots: 4..11
 enum ExtSlot { EX_IN = 0, EX_OUT = 1, EX_PARAM = 2, EX_COUNT = 3 };
 
-enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FALRK, OP_FASAND, OP_CONDBASE, OP_CONDBLK,
+enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FARED2, OP_FALRK, OP_FALRK2, OP_FASAND, OP_CONDBASE, OP_CONDBLK,
               OP_APPLY, OP_SPECTRAL, OP_FCOMBINE, OP_TRACE };
 
 struct Op {
@@ -84,8 +84,8 @@ struct Op {
     LnPeArgs ln;
     AttnArgs at;
     FaPoolArgs fp;
-    FaReducerArgs fr;
-    FaLrkArgs fl;
+    FaReducerArgs fr, fr2;     // fr2 / fl2: second axis of the merged two-axis launches
+    FaLrkArgs fl, fl2;
     FaSandwichArgs fs;
     CondBaseArgs cb;
     CondBlockArgs ck;

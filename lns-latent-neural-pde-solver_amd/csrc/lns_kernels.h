@@ -126,9 +126,15 @@ struct FaReducerArgs {                 // PoolingReducer on pooled rows [rows, C
     const float* w1_t;                 // [C][Hid]
     const float* w2_t;                 // [Hid][Out]
     const float* b2;                   // [Out]
-    float* u;
+    float* u;                          // may be null when the to_qk projection below is fused
+    // optional fused LowRankKernel.to_qk (1x1 conv Out -> Mqk on the reducer output): qk [B, Mqk, n]
+    const float* wqk_t; int ldqk;      // in-major [Out][ldqk] (the conv's fp32 pack)
+    const float* bqk;                  // [Mqk] or null
+    int Mqk; float* qk;
 };
 hipError_t launch_fa_reducer(const FaReducerArgs& a, hipStream_t s);
+// both axes (x: rows = B*H, y: rows = B*W) of one FABlock in ONE launch
+hipError_t launch_fa_reducer2(const FaReducerArgs& ax, const FaReducerArgs& ay, hipStream_t s);
 
 struct FaLrkArgs {                     // rotary + q k^T
     const float* qk;                   // [B, 2*heads*DK, n]
@@ -137,6 +143,7 @@ struct FaLrkArgs {                     // rotary + q k^T
     float* kmat;                       // [B, heads, n, n]
 };
 hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s);
+hipError_t launch_fa_lrk2(const FaLrkArgs& ax, const FaLrkArgs& ay, hipStream_t s);   // both axes in one launch
 
 struct FaSandwichArgs {
     const float* u; const float* kx; const float* ky;

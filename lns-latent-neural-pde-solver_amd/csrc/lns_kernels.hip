@@ -2107,17 +2107,22 @@ __global__ __launch_bounds__(256) void fa_reducer_kernel(FaReducerArgs a) {
 // through one LDS region per GEMM, the last one in chunks of 128 outputs.
 #define FARM_R 32
 #define FARM_RP 33
-__global__ __launch_bounds__(256) void fa_reducer_mfma_kernel(FaReducerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+static size_t fa_reducer_mfma_lds(const FaReducerArgs& a) {
+    const size_t wt = (size_t)std::max(std::max(a.C * a.Hid, a.Hid * 128), a.Out * 128);
+    return (wt + (size_t)(2 * a.C + a.Hid + (a.qk ? a.Out : 0)) * FARM_RP + 256) * 4;
+}
+
+__device__ __forceinline__ void fa_reducer_mfma_body(const FaReducerArgs& a, int block, char* smem) {
     const int C = a.C, Hid = a.Hid, Out = a.Out;
-    const int wt_floats = max(C * Hid, Hid * 128);
+    const int wt_floats = max(max(C * Hid, Hid * 128), Out * 128);
     float* Wt = reinterpret_cast<float*>(smem);           // current weight matrix / chunk, [k][m]
     float* X0 = Wt + wt_floats;                           // [C][RP]   pooled rows
     float* X1 = X0 + C * FARM_RP;                         // [C][RP]   to_in output / LayerNorm
     float* X2 = X1 + C * FARM_RP;                         // [Hid][RP] hidden
     float* red = X2 + Hid * FARM_RP;                      // [8][32] LayerNorm partials
+    float* X3 = red + 256;                                // [Out][RP] reducer output (only with the fused to_qk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
-    const long row0 = (long)blockIdx.x * FARM_R;
+    const long row0 = (long)block * FARM_R;
 
     // global -> LDS staging with 16 loads in flight per thread (a plain copy loop keeps one)
     auto stage = [&](float* dst, int n, auto src) __attribute__((always_inline)) {
@@ -2206,18 +2211,65 @@ __global__ __launch_bounds__(256) void fa_reducer_mfma_kernel(FaReducerArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + mt * 32 + drow(r, kh);
-                if (o < Out && row < a.rows) a.u[(bi * Out + o) * a.n + ii] = acc[r] + a.b2[o];
+                if (o < Out) {
+                    const float v = acc[r] + a.b2[o];
+                    if (a.u && row < a.rows) a.u[(bi * Out + o) * a.n + ii] = v;
+                    if (a.qk) X3[o * FARM_RP + l31] = v;
+                }
+            }
+        }
+    }
+    if (a.qk) {                                            // fused to_qk: qk[m][r] = sum_o wqk[o][m] * X3[o][r] (+ bias)
+        for (int m0 = 0; m0 < a.Mqk; m0 += 128) {
+            __syncthreads();
+            const int mc = min(128, a.Mqk - m0);
+            stage(Wt, Out * 128, [&](int i) {
+                const int k = i >> 7, o = i & 127;
+                return o < mc ? a.wqk_t[(long)k * a.ldqk + m0 + o] : 0.0f;
+            });
+            __syncthreads();
+            for (int mt = wave; mt * 32 < mc; mt += 4) {
+                const f32x16 acc = gemm_tile(Wt, 128, mt * 32, X3, Out);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + mt * 32 + drow(r, kh);
+                    if (m < a.Mqk && row < a.rows) a.qk[(bi * a.Mqk + m) * a.n + ii] = acc[r] + (a.bqk ? a.bqk[m] : 0.0f);
+                }
             }
         }
     }
 }
 
+__global__ __launch_bounds__(256) void fa_reducer_mfma_kernel(FaReducerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    fa_reducer_mfma_body(a, blockIdx.x, smem);
+}
+
+// both axes of a FABlock in one launch: the first nblk_x blocks run the x reducer, the rest the y reducer
+__global__ __launch_bounds__(256) void fa_reducer2_mfma_kernel(FaReducerArgs ax, FaReducerArgs ay, int nblk_x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < nblk_x) fa_reducer_mfma_body(ax, blockIdx.x, smem);
+    else fa_reducer_mfma_body(ay, blockIdx.x - nblk_x, smem);
+}
+
+static bool fa_reducer_mfma_ok(const FaReducerArgs& a) {
+    return a.C % 32 == 0 && a.Hid % 32 == 0 && a.C <= 256 && (!a.qk || a.Out % 2 == 0) && fa_reducer_mfma_lds(a) <= 160 * 1024;
+}
+
+hipError_t launch_fa_reducer2(const FaReducerArgs& ax, const FaReducerArgs& ay, hipStream_t s) {
+    if (!fa_reducer_mfma_ok(ax) || !fa_reducer_mfma_ok(ay)) return hipErrorInvalidValue;
+    const size_t lds = std::max(fa_reducer_mfma_lds(ax), fa_reducer_mfma_lds(ay));
+    const int nbx = (int)((ax.rows + FARM_R - 1) / FARM_R), nby = (int)((ay.rows + FARM_R - 1) / FARM_R);
+    hipLaunchKernelGGL(fa_reducer2_mfma_kernel, dim3(nbx + nby), dim3(256), lds, s, ax, ay, nbx);
+    return hipGetLastError();
+}
+
 hipError_t launch_fa_reducer(const FaReducerArgs& a, hipStream_t s) {
     static const bool scalar_only = getenv("LNS_FA_REDUCER_SCALAR") != nullptr;   // A/B knob
-    if (!scalar_only && a.C % 32 == 0 && a.Hid % 32 == 0 && a.C <= 256) {
-        const size_t wt = (size_t)std::max(a.C * a.Hid, a.Hid * 128);
-        const size_t lds = (wt + (size_t)(2 * a.C + a.Hid) * FARM_RP + 256) * 4;
-        if (lds <= 160 * 1024) {
+    if (a.qk && !(fa_reducer_mfma_ok(a) && !scalar_only)) return hipErrorInvalidValue;   // the fused projection needs the MFMA form
+    if (!scalar_only && fa_reducer_mfma_ok(a)) {
+        const size_t lds = fa_reducer_mfma_lds(a);
+        {
             const unsigned nb = (unsigned)((a.rows + FARM_R - 1) / FARM_R);
             hipLaunchKernelGGL(fa_reducer_mfma_kernel, dim3(nb), dim3(256), lds, s, a);
             return hipGetLastError();
@@ -2235,8 +2287,20 @@ hipError_t launch_fa_reducer(const FaReducerArgs& a, hipStream_t s) {
 // FABlock2D LowRankKernel: rotary embedding of q,k then K = q k^T per (b,head)
 // (no softmax, no scaling).  q',k' staged in LDS as [d][n_pad]; MFMA tiles.
 // ===========================================================================
+__device__ __forceinline__ void fa_lrk_body(const FaLrkArgs& a, char* smem);
+
 __global__ __launch_bounds__(256) void fa_lrk_kernel(FaLrkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    fa_lrk_body(a, smem);
+}
+
+__global__ __launch_bounds__(256) void fa_lrk2_kernel(FaLrkArgs ax, FaLrkArgs ay) {   // blockIdx.z: axis
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.z == 0) fa_lrk_body(ax, smem);
+    else fa_lrk_body(ay, smem);
+}
+
+__device__ __forceinline__ void fa_lrk_body(const FaLrkArgs& a, char* smem) {
     const int n = a.n, DK = a.DK, half = DK >> 1;
     const int nt = (n + 31) / 32, npad = nt * 32;
     float* qs = reinterpret_cast<float*>(smem);   // [DK][npad]
@@ -2288,6 +2352,15 @@ __global__ __launch_bounds__(256) void fa_lrk_kernel(FaLrkArgs a) {
             if (i < n && j < n) ob[(long)i * n + j] = acc[r];
         }
     }
+}
+
+hipError_t launch_fa_lrk2(const FaLrkArgs& ax, const FaLrkArgs& ay, hipStream_t s) {
+    if (ax.heads != ay.heads || ax.B != ay.B || ax.DK != ay.DK) return hipErrorInvalidValue;
+    const int npx = ((ax.n + 31) / 32) * 32, npy = ((ay.n + 31) / 32) * 32;
+    const size_t lds = (size_t)2 * ax.DK * std::max(npx, npy) * 4;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fa_lrk2_kernel, dim3(ax.heads, ax.B, 2), dim3(256), lds, s, ax, ay);
+    return hipGetLastError();
 }
 
 hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s) {
@@ -3146,7 +3219,9 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false>))
     LNS_SET_LDS(fa_reducer_mfma_kernel)
+    LNS_SET_LDS(fa_reducer2_mfma_kernel)
     LNS_SET_LDS(fa_lrk_kernel)
+    LNS_SET_LDS(fa_lrk2_kernel)
     LNS_SET_LDS(fa_pool_kernel)
     LNS_SET_LDS(fa_reducer_kernel)
 #undef LNS_SET_LDS

@@ -1669,6 +1669,9 @@ hipError_t launch_conv1_thin(const ConvArgs& a, hipStream_t s) {
 // GroupNorm statistics: one block per (group, sample); two-pass (mean, then
 // centred second moment) over a contiguous (C/groups)*HW slab.  HBM-bound.
 // ===========================================================================
+// NV: float4 per thread held in registers by the single-read path (0: streaming two-read path only); small NV keeps
+// the register count -- and with it the number of resident blocks -- right for small slabs
+template <int NVT>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsArgs a) {
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y;
@@ -1679,8 +1682,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsArgs a) {
     float s = 0.0f, q = 0.0f;
     float mean;
     const bool vec = !pm && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15) == 0);
-    constexpr int NV = 32;                                  // float4 per thread held in registers
-    if (vec && (n >> 2) <= (long)NV * 256) {
+    constexpr int NV = NVT > 0 ? NVT : 1;
+    if (NVT > 0 && vec && (n >> 2) <= (long)NV * 256) {
         // the whole slab fits the block's registers: ONE read (all loads in flight), exact two-pass statistics,
         // the same per-thread element order and reduction tree as the streaming path below
         const float4* x4 = reinterpret_cast<const float4*>(xs);
@@ -1841,7 +1844,14 @@ hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s) {
         hipLaunchKernelGGL(gn_partial_kernel, dim3(a.C, a.B), dim3(256), 0, s, a, part);
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, s, a, static_cast<const float*>(part));
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a);
+        const long n = (long)(a.C / a.groups) * a.HW;
+        const long per = ((n >> 2) + 255) / 256;            // float4 per thread if the slab is held in registers
+        dim3 grid(a.groups, a.B);
+        if ((n & 3) || a.premul || per > 32) hipLaunchKernelGGL((gn_stats_kernel<0>), grid, dim3(256), 0, s, a);
+        else if (per <= 1) hipLaunchKernelGGL((gn_stats_kernel<1>), grid, dim3(256), 0, s, a);
+        else if (per <= 4) hipLaunchKernelGGL((gn_stats_kernel<4>), grid, dim3(256), 0, s, a);
+        else if (per <= 8) hipLaunchKernelGGL((gn_stats_kernel<8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gn_stats_kernel<32>), grid, dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }

@@ -1769,6 +1769,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsArgs a) {
 // every (sample, channel) plane its own block (mean and centred second moment), stage 2 merges
 // the channels of a group with the pairwise update of Chan et al. -- exact two-pass numerics per
 // plane, parallelism B*C instead of B*groups.
+// Small groups (slab <= 4 KB, e.g. GroupNorm(32, 128) on a 16x16 latent): one WAVE per (group, sample), the slab in
+// 4 float4 per lane, wave shuffles only -- no block barrier, 4 groups per 256-thread block.
+__global__ __launch_bounds__(256) void gn_stats_wave_kernel(GnStatsArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (g >= a.groups) return;
+    const int cg = a.C / a.groups;
+    const int n = cg * a.HW, n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(a.x + (long)b * a.x_bs + (long)g * cg * a.HW);
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = lane + u * 64;
+        v[u] = i < n4 ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + u * 64 < n4) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + u * 64 < n4) {
+            const float d0 = v[u].x - mean, d1 = v[u].y - mean, d2 = v[u].z - mean, d3 = v[u].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + a.eps);
+    for (int c = lane; c < cg; c += 64) {
+        const int ch = g * cg + c;
+        const float ga = a.gamma ? a.gamma[ch] : 1.0f;
+        const float be = a.beta ? a.beta[ch] : 0.0f;
+        a.ss[((long)b * a.C + ch) * 2] = rstd * ga;
+        a.ss[((long)b * a.C + ch) * 2 + 1] = be - mean * rstd * ga;
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnStatsArgs a, float* part) {
     __shared__ float red[4];
     const int c = blockIdx.x, b = blockIdx.y;
@@ -1847,7 +1884,10 @@ hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s) {
         const long n = (long)(a.C / a.groups) * a.HW;
         const long per = ((n >> 2) + 255) / 256;            // float4 per thread if the slab is held in registers
         dim3 grid(a.groups, a.B);
-        if ((n & 3) || a.premul || per > 32) hipLaunchKernelGGL((gn_stats_kernel<0>), grid, dim3(256), 0, s, a);
+        const bool al16 = (a.x_bs & 3) == 0 && ((a.HW * (a.C / a.groups)) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+        if (!(n & 3) && !a.premul && n <= 1024 && al16)     // layer-static choice (pointers are 256-byte aligned arena slots)
+            hipLaunchKernelGGL(gn_stats_wave_kernel, dim3((a.groups + 3) / 4, a.B), dim3(256), 0, s, a);
+        else if ((n & 3) || a.premul || per > 32) hipLaunchKernelGGL((gn_stats_kernel<0>), grid, dim3(256), 0, s, a);
         else if (per <= 1) hipLaunchKernelGGL((gn_stats_kernel<1>), grid, dim3(256), 0, s, a);
         else if (per <= 4) hipLaunchKernelGGL((gn_stats_kernel<4>), grid, dim3(256), 0, s, a);
         else if (per <= 8) hipLaunchKernelGGL((gn_stats_kernel<8>), grid, dim3(256), 0, s, a);

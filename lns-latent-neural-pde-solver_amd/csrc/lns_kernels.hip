@@ -2867,7 +2867,10 @@ static hipError_t launch_fa_sandwich_t(const FaSandwichArgs& a, hipStream_t s) {
     // bf16x3 form whenever its LDS image fits (a function of H, W only, so the choice never depends on the batch)
     static const bool fp32_only = getenv("LNS_FA_SANDWICH_FP32") != nullptr;
     if (!fp32_only && fa_sandwich_b_lds_bytes(HT, WT) <= 160 * 1024) {
-        int ppb = 16;
+        // planes per block: the Kx/Ky staging (load + split) is paid once per block, so as many planes as still leave
+        // >= 2 blocks per CU
+        static const int ppb_max = getenv("LNS_FA_PPB") ? atoi(getenv("LNS_FA_PPB")) : 64;
+        int ppb = ppb_max;
         while (ppb > 4 && (long)a.B * a.heads * ((a.C + ppb - 1) / ppb) < 512) ppb >>= 1;
         dim3 grid((a.C + ppb - 1) / ppb, a.heads, a.B);
         const size_t ldsb = fa_sandwich_b_lds_bytes(HT, WT);

@@ -11,6 +11,10 @@ L = _lib.lib()
 cases = {
     "dec13": dict(B=64, Cin=64, Cout=64, H=64, W=64, k=3, up=(128, 128), ss=True, act=1),
     "lat": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0),
+    "lat32": dict(B=64, Cin=32, Cout=128, H=16, W=16, k=3, ss=True, act=0),
+    "lat64": dict(B=64, Cin=64, Cout=128, H=16, W=16, k=3, ss=True, act=0),
+    "lat256": dict(B=64, Cin=256, Cout=128, H=16, W=16, k=3, ss=True, act=0),
+    "lat512": dict(B=64, Cin=512, Cout=128, H=16, W=16, k=3, ss=True, act=0),
     "c64": dict(B=64, Cin=64, Cout=64, H=64, W=64, k=3, ss=True, act=1),
     "inproj": dict(B=64, Cin=64, Cout=512, H=64, W=64, k=1, ss=True, act=0),
 }

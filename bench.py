@@ -85,7 +85,8 @@ def traffic_from_profiles(kernel):
             d = json.load(f)
         k = d["kernels"][kernel]
         return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "unit": "B", "source": os.path.basename(files[-1]),
-                "profiled_kernel": k["kernel"]}
+                "profiled_kernel": k["kernel"], "fetch_bytes_per_launch": k["fetch_bytes_per_launch"],
+                "write_bytes_per_launch": k["write_bytes_per_launch"]}
     except Exception:
         return None
 
@@ -213,7 +214,10 @@ def main():
                               % (F16_MFMA_PEAK_TFLOPS, SPLIT_EXEC_PER_ALGO),
                 "executed_f16_tflops": ach * SPLIT_EXEC_PER_ALGO,
                 "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": traffic_from_profiles("conv3x3"), "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
+                # HBM bytes per launch from the committed PMC passes (number, bytes); provenance in traffic_detail
+                "traffic": (traffic_from_profiles("conv3x3") or {}).get("hbm_bytes_per_launch"),
+                "traffic_detail": traffic_from_profiles("conv3x3"),
+                "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
                 "algorithmic_flop_per_launch": k["flops"] / k["launches"],
                 "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
                 "mode": "single-stream diagnostic pass (python bench.py --serial reproduces it under rocprofv3); the class "

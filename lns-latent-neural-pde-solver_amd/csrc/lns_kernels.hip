@@ -582,9 +582,12 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 // accumulators, then bias / per-sample add / activation / fused second 1x1 conv (fp32 MFMA, the
 // accumulator tile as B operand, see conv_mfma_kernel) / residual, and the coalesced stores.
 // pix[nt]: flat output pixel of this lane in pixel tile nt, or -1.
+// addv: LDS vector [TM] of (bias + per-sample add) of this cout tile, staged in the prologue so that the epilogue
+// does not start with a round trip to L2 (null: read bias / badd from global memory here).
 template <int NT, bool FUSE2, int MT = 2>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
-                                               const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds) {
+                                               const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
+                                               const float* addv = nullptr) {
     constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
     static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
     f32x16 acc[MT][NT];
@@ -597,7 +600,16 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     const int HWo = a.Hout * a.Wout;
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
-    if (a.bias || a.badd) {
+    if (addv) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float add = addv[mt * 32 + drow(r, kh)];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
+            }
+    } else if (a.bias || a.badd) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int cob = ct * TM + mt * 32 + 4 * kh;
@@ -733,8 +745,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     char* lds = smem;                                                  // 2 x [Xb | Wb]
     char* zunit = lds + 2 * buf_bytes;                                 // one all-zero 16-byte unit
     float* ssl = reinterpret_cast<float*>(zunit + 16);                 // [Cin_pad][2]
-    int* rmap = reinterpret_cast<int*>(ssl + a.Cin_pad * 2);
-    int* cmap = rmap + PH;
+    float* addv = ssl + a.Cin_pad * 2;                                 // [TM] bias + per-sample add of this cout tile
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -749,30 +760,41 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     const bool has_ss = a.ss != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
 
-    for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
-        ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
-    for (int i = tid; i < PH; i += NTHR) rmap[i] = a.rowmap[ty * BH * a.stride + i];
-    for (int i = tid; i < PW; i += NTHR) cmap[i] = a.colmap[tx * BW * a.stride + i];
-    if (tid < 4) reinterpret_cast<unsigned*>(zunit)[tid] = 0u;
-    __syncthreads();
-
-    // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or -1.
-    // Threads past the end of the patch stage into the sink unit, so the K loop has no branches.
+    // Prologue: everything the first stage needs is requested from global memory up front -- the row/column source
+    // maps of this thread's patch units (direct loads, no LDS round trip), the GroupNorm scale/shift table and the
+    // epilogue's add vector (to LDS) -- so the block pays ONE memory latency before its first patch loads, and the
+    // epilogue none.
     int udm[NU], uslot[NU];
     float uok[NU];
+    {
+        int sy[NU], sx[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int p = tid + u * NTHR;
-        int d = -1;
-        if (p < PLANE) {
-            const int py = p / PW, px = p - py * PW;
-            const int sy = rmap[py], sx = cmap[px];
-            if (sy >= 0 && sx >= 0) d = sy * a.Win + sx;
+        for (int u = 0; u < NU; ++u) {
+            const int p = tid + u * NTHR;
+            const int pc = p < PLANE ? p : 0;
+            const int py = pc / PW, px = pc - py * PW;
+            sy[u] = a.rowmap[ty * BH * a.stride + py];
+            sx[u] = a.colmap[tx * BW * a.stride + px];
         }
-        udm[u] = d >= 0 ? d : 0;
-        uok[u] = d >= 0 ? (SPL == 2 ? CONVF_XSCALE : 1.0f) : 0.0f;     // fp16 split: activations are staged scaled
-        uslot[u] = (p < PLANE ? p : PLANE) * 16;
+        for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
+            ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+        if (tid < TM) {
+            const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
+            addv[tid] = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
+        }
+        if (tid < 4) reinterpret_cast<unsigned*>(zunit)[tid] = 0u;
+        // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or none.
+        // Threads past the end of the patch stage into the sink unit, so the K loop has no branches.
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int p = tid + u * NTHR;
+            const bool ok = p < PLANE && sy[u] >= 0 && sx[u] >= 0;
+            udm[u] = ok ? sy[u] * a.Win + sx[u] : 0;
+            uok[u] = ok ? (SPL == 2 ? CONVF_XSCALE : 1.0f) : 0.0f;     // fp16 split: activations are staged scaled
+            uslot[u] = (p < PLANE ? p : PLANE) * 16;
+        }
     }
+    __syncthreads();
     // weight slab of this cout tile: host slabs hold 64 couts per (split, tap) row; a 32-cout block copies its half
     // of every row.  16 bytes per thread-slot.
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * SLAB64 +
@@ -974,7 +996,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
         pix[nt] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : -1;
     }
-    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds);
+    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, (a.bias || a.badd) ? addv : nullptr);
 }
 
 // ===========================================================================
@@ -1410,7 +1432,7 @@ hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s) {
 
 size_t convb_lds_bytes(const ConvArgs& a, int tm, int spl) {
     const size_t pp1 = (size_t)a.PH * a.PW + 1;
-    return 2 * (spl * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + a.PH + a.PW) * 4 + 16;
+    return 2 * (spl * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + 64) * 4 + 16;
 }
 
 bool convb_fits(const ConvArgs& a) {

@@ -648,6 +648,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
         // permuted inside every 16-block so that those 8 channels are 8 consecutive k positions of the A operand.
         constexpr int W2W = TM + 8;                               // row stride in fp16 elements (16-byte aligned rows)
         unsigned short* W2s = reinterpret_cast<unsigned short*>(lds);   // [2][co2][W2W]
+        float* b2s = reinterpret_cast<float*>(W2s + 2 * TM * W2W);      // [TM] bias of the second conv
         __syncthreads();
         {
             float v[TM * TM / NTHR];
@@ -666,6 +667,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 W2s[(0 * TM + co2) * W2W + kp] = __builtin_bit_cast(unsigned short, hh);
                 W2s[(1 * TM + co2) * W2W + kp] = __builtin_bit_cast(unsigned short, ll);
             }
+            if (tid < TM) b2s[tid] = a.bias2 ? a.bias2[tid] : 0.0f;
         }
         __syncthreads();
         const float unscale2 = 1.0f / (CONVF_XSCALE * a.w2scale);
@@ -701,7 +703,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             for (int m2 = 0; m2 < MT; ++m2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[m2][nt][r] = (a2h[m2][r] + a2l[m2][r]) * unscale2 + (a.bias2 ? a.bias2[m2 * 32 + drow(r, kh)] : 0.0f);
+                    acc[m2][nt][r] = (a2h[m2][r] + a2l[m2][r]) * unscale2 + b2s[m2 * 32 + drow(r, kh)];
         }
     }
 #pragma unroll
@@ -1020,6 +1022,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds = smem;                                                  // 2 x [Xb | Wb]
     float* ssl = reinterpret_cast<float*>(lds + 2 * BUF);              // [Cin_pad][2]
+    float* addv = ssl + a.Cin_pad * 2;                                 // [TM] bias + per-sample add of this cout tile
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -1035,6 +1038,10 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
 
     for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
         ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+    if (tid < TM) {
+        const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
+        addv[tid] = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
+    }
     __syncthreads();
 
     // two staging units (pixel, octet) per thread.  VEC2 (even H*W): two adjacent pixels of one octet, fetched
@@ -1215,7 +1222,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         const int p = p0 + wn * 32 + l31;
         pix[0] = p < a.Hout * a.Wout ? p : -1;
     }
-    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds);
+    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, (a.bias || a.badd) ? addv : nullptr);
 }
 
 // Input-stationary form of the 1x1 kernel for narrow inputs (Cin_pad <= 64) feeding many output channels:
@@ -1399,7 +1406,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
     }
 }
 
-size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 16; }
+size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 64 * 4 + 16; }
 
 bool convb1_fits(const ConvArgs& a) {
     return a.ks == 1 && a.stride == 1 && (a.Cin_pad % 32) == 0 && a.wb != nullptr && convb1_lds_bytes(a) <= 150 * 1024;

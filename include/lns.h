@@ -221,6 +221,19 @@ int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int
 int lns_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, int HW, float mean, float std, float eps,
                       float* frame_out, float* seq_out, float* scratch, void* stream);
 
+/* Same metric with per-channel statistics and the boundary handling of the other datasets' denormalize():
+ *   v = x*std[c] + mean[c]                     (dataset/Stage2_SW.py:60-72, per-channel u / v / pres stats)
+ *   flags[c] & LNS_METRIC_ZERO_WALLS: first/last row and column set to 0 after the affine map
+ *                                              (closed-tank velocities, dataset/twophase_flow_stage2.py:370-383)
+ *   flags[c] & LNS_METRIC_CLAMP:      v clamped to [clamp_lo, clamp_hi]   (VOF channel, :388, [0, 1+1e-8])
+ * applied to both yhat and y as train_stage2_twophase*.py:251-254 / :287-290 do.  mean/std/flags: HOST arrays of C
+ * entries (NULL = 0 / 1 / 0); C <= 8. */
+#define LNS_METRIC_ZERO_WALLS 1
+#define LNS_METRIC_CLAMP 2
+int lns_metric_rel_l2_ch(const float* yhat, const float* y, int B, int T, int C, int H, int W, const float* mean_host,
+                         const float* std_host, const int* flags_host, float clamp_lo, float clamp_hi, float eps,
+                         float* frame_out, float* seq_out, float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

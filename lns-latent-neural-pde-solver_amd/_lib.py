@@ -60,7 +60,7 @@ SYMBOLS = [
     "lns_encode", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent",
     "lns_trace_enable", "lns_trace_count", "lns_trace_info", "lns_trace_copy",
     "lns_timing_enable", "lns_timing_count", "lns_timing_info",
-    "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block", "lns_metric_rel_l2",
+    "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block", "lns_metric_rel_l2", "lns_metric_rel_l2_ch",
 ]
 
 _lib = None
@@ -124,5 +124,7 @@ def lib():
     L.lns_op_fourier_block.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lns_metric_rel_l2.argtypes = [vp, vp, i, i, i, i, c.c_float, c.c_float, c.c_float, vp, vp, vp, vp]
     L.lns_metric_rel_l2.restype = i
+    L.lns_metric_rel_l2_ch.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp, c.c_float, c.c_float, c.c_float, vp, vp, vp, vp]
+    L.lns_metric_rel_l2_ch.restype = i
     _lib = L
     return L

@@ -1680,6 +1680,23 @@ int lns_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, in
     return LNS_OK;
 }
 
+int lns_metric_rel_l2_ch(const float* yhat, const float* y, int B, int T, int C, int H, int W, const float* mean_host,
+                         const float* std_host, const int* flags_host, float clamp_lo, float clamp_hi, float eps,
+                         float* frame_out, float* seq_out, float* scratch, void* stream) {
+    if (!yhat || !y || !scratch || B <= 0 || T <= 0 || C <= 0 || C > LNS_METRIC_MAX_CH || H <= 0 || W <= 0 ||
+        (!frame_out && !seq_out))
+        return LNS_EINVAL;
+    MetricChannelSpec spec;
+    for (int c = 0; c < LNS_METRIC_MAX_CH; ++c) {
+        spec.mean[c] = (mean_host && c < C) ? mean_host[c] : 0.0f;
+        spec.std[c] = (std_host && c < C) ? std_host[c] : 1.0f;
+        spec.flags[c] = (flags_host && c < C) ? flags_host[c] : 0;
+    }
+    spec.lo = clamp_lo; spec.hi = clamp_hi;
+    OPCHK(launch_metric_rel_l2_ch(yhat, y, B, T, C, H, W, spec, eps, frame_out, seq_out, scratch, static_cast<hipStream_t>(stream)));
+    return LNS_OK;
+}
+
 int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, float eps, const float* gamma_host,
                            const float* beta_host, const float* premul, float* ss, void* stream) {
     if (!x || !ss || C % groups) return LNS_EINVAL;

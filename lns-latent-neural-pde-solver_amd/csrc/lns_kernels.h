@@ -199,6 +199,15 @@ hipError_t launch_vec_linear(const VecLinearArgs& a, hipStream_t s);
 // fused denormalise + relative-L2 metric of a rollout (scratch: B*T*C*2 floats)
 hipError_t launch_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, int HW, float mean, float sd, float eps,
                                 float* frame_out, float* seq_out, float* scratch, hipStream_t s);
+#define LNS_METRIC_MAX_CH 8
+struct MetricChannelSpec {
+    float mean[LNS_METRIC_MAX_CH], std[LNS_METRIC_MAX_CH];
+    int flags[LNS_METRIC_MAX_CH];      // 1: zero the four wall rows/columns, 2: clamp to [lo, hi]
+    float lo, hi;
+};
+hipError_t launch_metric_rel_l2_ch(const float* yhat, const float* y, int B, int T, int C, int H, int W,
+                                   const MetricChannelSpec& spec, float eps, float* frame_out, float* seq_out,
+                                   float* scratch, hipStream_t s);
 
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
 

@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
         addv[tid] = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
     }
-    __syncthreads();
+    // (the barrier that publishes ssl / addv sits behind the first stage's global loads in k_loop: one memory
+    //  latency before the first split instead of two)
 
     // two staging units (pixel, octet) per thread.  VEC2 (even H*W): two adjacent pixels of one octet, fetched
     // with 8-byte loads; otherwise one pixel, octets o and o + 2.
@@ -1135,6 +1136,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         for (int cp = 0; cp < 4; ++cp) load_pairs(cp, 0);
 #pragma unroll
         for (int i = 0; i < NWU; ++i) load_w(i, 0);
+        __syncthreads();                                   // ssl / addv visible
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -1253,7 +1255,6 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
 
     for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
         ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
-    __syncthreads();
 
     // ---- stage the whole pixel tile (all channels) ----------------------------------
     {
@@ -1283,6 +1284,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
                     }
                 }
             }
+            if (st == 0) __syncthreads();                   // ssl visible (behind the first stage's global loads)
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 unsigned hq[4], mq[4], lq[4];
@@ -3205,6 +3207,37 @@ __global__ __launch_bounds__(256) void metric_plane_kernel(const float* yhat, co
     }
 }
 
+// Per-channel statistics and the two-phase dataset's boundary handling (dataset/twophase_flow_stage2.py:370-390,
+// dataset/Stage2_SW.py:60-72): v = x*std[c] + mean[c]; flag 1: the four wall rows/columns are set to zero;
+// flag 2: v is clamped to [lo, hi].  Both tensors go through the same map, as the reference denormalises both.
+__global__ __launch_bounds__(256) void metric_plane_ch_kernel(const float* yhat, const float* y, int C, int H, int W,
+                                                              MetricChannelSpec spec, float* part) {
+    __shared__ float red[8];
+    const long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float sd = spec.std[c], mean = spec.mean[c];
+    const bool walls = spec.flags[c] & 1, clampv = spec.flags[c] & 2;
+    const int HW = H * W;
+    const float* a = yhat + plane * HW;
+    const float* g = y + plane * HW;
+    float d2 = 0.0f, g2 = 0.0f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int r = i / W, col = i - r * W;
+        float p = a[i] * sd + mean, q = g[i] * sd + mean;
+        if (walls && (r == 0 || r == H - 1 || col == 0 || col == W - 1)) { p = 0.0f; q = 0.0f; }
+        if (clampv) { p = fminf(fmaxf(p, spec.lo), spec.hi); q = fminf(fmaxf(q, spec.lo), spec.hi); }
+        const float e = p - q;
+        d2 += e * e; g2 += q * q;
+    }
+    d2 = wave_sum(d2); g2 = wave_sum(g2);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = d2; red[4 + (threadIdx.x >> 6)] = g2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[plane * 2] = (red[0] + red[1]) + (red[2] + red[3]);
+        part[plane * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
 __global__ void metric_finish_kernel(const float* part, int B, int T, int C, float eps, float* frame_out, float* seq_out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (b, c)
     if (idx >= B * C) return;
@@ -3222,6 +3255,14 @@ __global__ void metric_finish_kernel(const float* part, int B, int T, int C, flo
 hipError_t launch_metric_rel_l2(const float* yhat, const float* y, int B, int T, int C, int HW, float mean, float sd, float eps,
                                 float* frame_out, float* seq_out, float* scratch, hipStream_t s) {
     hipLaunchKernelGGL(metric_plane_kernel, dim3((unsigned)((long)B * T * C)), dim3(256), 0, s, yhat, y, HW, mean, sd, scratch);
+    hipLaunchKernelGGL(metric_finish_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, scratch, B, T, C, eps, frame_out, seq_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_metric_rel_l2_ch(const float* yhat, const float* y, int B, int T, int C, int H, int W,
+                                   const MetricChannelSpec& spec, float eps, float* frame_out, float* seq_out,
+                                   float* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(metric_plane_ch_kernel, dim3((unsigned)((long)B * T * C)), dim3(256), 0, s, yhat, y, C, H, W, spec, scratch);
     hipLaunchKernelGGL(metric_finish_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, scratch, B, T, C, eps, frame_out, seq_out);
     return hipGetLastError();
 }

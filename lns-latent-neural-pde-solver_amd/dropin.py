@@ -252,9 +252,30 @@ class LatentDynamics(_Hosted):
     def z_to_x(self, z):
         return self._ae.decode(z)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("teacher-forced training rollout (train_stage2_ns2d.py:126-141) needs "
-                                  "autograd and is outside the accelerated inference path")
+    def forward(self, z_in, z_out, *rest):
+        """forward(z_in, z_out, loss_fn) -- conditional: forward(z_in, z_out, param, loss_fn): the loss VALUE of the
+        latent rollout started at z_in[:, 0] against the pre-encoded targets z_out [B,t_out,c,h,w]
+        (train_stage2_ns2d.py:126-141; conditional train_stage2_twophase_conditional.py:160-175), i.e. the quantity
+        a stage-2 validation pass reports.  The HIP path has no backward: calling it with autograd enabled raises
+        instead of returning a loss that silently carries no gradient."""
+        if torch.is_grad_enabled():
+            raise NotImplementedError("the latent rollout runs on hand-written HIP kernels without a backward pass: "
+                                      "call forward() under torch.no_grad() for the loss value (training the "
+                                      "propagator needs autograd and is outside the accelerated inference path)")
+        param = None
+        if self._conditional:
+            if len(rest) != 2:
+                raise TypeError("forward() takes (z_in, z_out, param, loss_fn)")
+            param, loss_fn = rest
+        else:
+            if len(rest) != 1:
+                raise TypeError("forward() takes (z_in, z_out, loss_fn)")
+            loss_fn, = rest
+        if z_in.dim() != 5 or z_in.shape[1] != 1:
+            raise AssertionError("z_in must be [B,1,c,h,w] (t_in == 1)")
+        z0 = z_in[:, 0].contiguous()
+        z_pred, _ = self._engine(z0).rollout_latent(z0, z_out.shape[1], param=param, to_x=False)
+        return loss_fn(z_pred, z_out)
 
     @staticmethod
     def _fields(x):

@@ -5,6 +5,10 @@ dataset encode.  Mirrors the reference call sites:
     frame_wise = relative_lp_loss(y_hat, y, reduce_dim=(3, 4), p=2)        # train_stage2_ns2d.py:253-257
     seq_wise   = relative_lp_loss(y_hat, y, reduce_dim=(1, 3, 4), p=2)
     dataset.encode_dataset(vq_ae, device)                                   # ns2d_fno_stage2_simpleae.py:81-93
+
+The other datasets' denormalize() (per-channel statistics, dataset/Stage2_SW.py:60-72; closed-tank wall velocities
+zeroed and VOF clamped, dataset/twophase_flow_stage2.py:370-390) are the same kernel with a per-channel spec:
+`relative_l2(..., mean=[...], std=[...], zero_wall_channels=(0, 1), clamp_channels=(3,))` or `twophase_spec(...)`.
 """
 import ctypes
 
@@ -13,10 +17,18 @@ import torch
 from . import _lib
 
 
-def relative_l2(y_hat, y, mean=0.0, std=1.0, eps=1e-8):
+def twophase_spec(vel_mean, vel_std, prs_mean, prs_std):
+    """Keyword arguments for relative_l2 that restate TwoPhaseFlow dataset denormalisation
+    (dataset/twophase_flow_stage2.py:370-390): channels (u, v, p, vof)."""
+    return dict(mean=[vel_mean, vel_mean, prs_mean, 0.0], std=[vel_std, vel_std, prs_std, 1.0],
+                zero_wall_channels=(0, 1), clamp_channels=(3,), clamp=(0.0, 1.0 + 1e-8))
+
+
+def relative_l2(y_hat, y, mean=0.0, std=1.0, eps=1e-8, zero_wall_channels=(), clamp_channels=(), clamp=(0.0, 1.0 + 1e-8)):
     """(frame_wise [B,T,C], seq_wise [B,C]) relative L2 errors of a normalised rollout y_hat against the normalised
-    ground truth y, both [B,T,C,H,W], after the affine denormalisation x*std + mean.  One HIP pass over both
-    tensors (lns_metric_rel_l2); CPU tensors raise -- there is no CPU fallback."""
+    ground truth y, both [B,T,C,H,W], after the dataset's denormalisation: x*std + mean with scalar or per-channel
+    statistics, optionally the wall rows/columns of `zero_wall_channels` zeroed and `clamp_channels` clamped.
+    One HIP pass over both tensors; CPU tensors raise -- there is no CPU fallback."""
     if not (y_hat.is_cuda and y.is_cuda):
         raise RuntimeError("lns_amd.metrics.relative_l2 needs CUDA/HIP tensors (no CPU fallback)")
     if y_hat.shape != y.shape or y_hat.dim() != 5:
@@ -28,9 +40,27 @@ def relative_l2(y_hat, y, mean=0.0, std=1.0, eps=1e-8):
     seq = torch.empty((B, C), dtype=torch.float32, device=y.device)
     scratch = torch.empty((B * T * C * 2,), dtype=torch.float32, device=y.device)
     L = _lib.lib()
-    rc = L.lns_metric_rel_l2(y_hat.data_ptr(), y.data_ptr(), B, T, C, H * W, float(mean), float(std), float(eps),
-                             frame.data_ptr(), seq.data_ptr(), scratch.data_ptr(),
-                             ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
+    per_channel = (not isinstance(mean, (int, float))) or (not isinstance(std, (int, float))) or \
+        len(zero_wall_channels) > 0 or len(clamp_channels) > 0
+    if not per_channel:
+        rc = L.lns_metric_rel_l2(y_hat.data_ptr(), y.data_ptr(), B, T, C, H * W, float(mean), float(std), float(eps),
+                                 frame.data_ptr(), seq.data_ptr(), scratch.data_ptr(), stream)
+    else:
+        def per_c(v):
+            v = [float(v)] * C if isinstance(v, (int, float)) else [float(e) for e in v]
+            if len(v) != C:
+                raise ValueError("per-channel statistics need %d entries" % C)
+            return (ctypes.c_float * C)(*v)
+        flags = [0] * C
+        for c in zero_wall_channels:
+            flags[c] |= 1
+        for c in clamp_channels:
+            flags[c] |= 2
+        m, sd, fl = per_c(mean), per_c(std), (ctypes.c_int * C)(*flags)
+        rc = L.lns_metric_rel_l2_ch(y_hat.data_ptr(), y.data_ptr(), B, T, C, H, W, m, sd, fl, float(clamp[0]),
+                                    float(clamp[1]), float(eps), frame.data_ptr(), seq.data_ptr(),
+                                    scratch.data_ptr(), stream)
     if rc != 0:
         raise RuntimeError("lns_metric_rel_l2 failed (rc=%d)" % rc)
     return frame, seq

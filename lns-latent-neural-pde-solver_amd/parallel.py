@@ -69,3 +69,19 @@ class ChunkedGatherRollout:
         if self.gathered is None:
             return torch.cat(self.bufs, dim=1)
         return torch.cat(self.gathered, dim=1)
+
+
+def gather_metrics(frame, seq, group=None):
+    """Validation over sharded trajectories without moving the fields: each rank reduces its own decoded rollout to
+    the frame-wise [b,T,C] and sequence-wise [b,C] errors (lns_amd.metrics.relative_l2, one pass over its shard) and
+    only those are all-gathered -- KBs per rank instead of the [b,T,C,H,W] fields.  Returns the
+    concatenation over ranks in rank order, i.e. the rows of train_stage2_ns2d.py:254-257 for the global batch.
+    All ranks must hold the same local batch size."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return frame, seq
+    world = dist.get_world_size(group)
+    f_all = torch.empty((world * frame.shape[0],) + tuple(frame.shape[1:]), dtype=frame.dtype, device=frame.device)
+    s_all = torch.empty((world * seq.shape[0],) + tuple(seq.shape[1:]), dtype=seq.dtype, device=seq.device)
+    dist.all_gather_into_tensor(f_all, frame.contiguous(), group=group)
+    dist.all_gather_into_tensor(s_all, seq.contiguous(), group=group)
+    return f_all, s_all

@@ -628,10 +628,53 @@ def denormalize(x, mean, std):
     return np.asarray(x, np.float64) * std + mean
 
 
-def rollout_metrics(y_hat, y, mean=0.0, std=1.0, eps=1e-8):
-    """The validate_loop metric pair of train_stage2_ns2d.py:253-257 on [B,T,C,H,W] arrays."""
-    yh, yt = denormalize(y_hat, mean, std), denormalize(y, mean, std)
+def denormalize_channels(x, mean, std):
+    """dataset/Stage2_SW.py:60-72: per-channel affine map on [..., C, H, W]."""
+    x = np.asarray(x, np.float64)
+    m = np.asarray(mean, np.float64).reshape(-1, 1, 1)
+    s = np.asarray(std, np.float64).reshape(-1, 1, 1)
+    return x * s + m
+
+
+def denormalize_twophase(x, vel_mean, vel_std, prs_mean, prs_std):
+    """dataset/twophase_flow_stage2.py:370-390: velocities denormalised then zeroed on the four closed walls,
+    pressure denormalised, VOF clamped to [0, 1+1e-8].  x [..., 4, H, W]."""
+    x = np.array(x, np.float64, copy=True)
+    x[..., :2, :, :] = x[..., :2, :, :] * vel_std + vel_mean
+    x[..., :2, 0, :] = 0.0
+    x[..., :2, -1, :] = 0.0
+    x[..., :2, :, 0] = 0.0
+    x[..., :2, :, -1] = 0.0
+    x[..., 2, :, :] = x[..., 2, :, :] * prs_std + prs_mean
+    x[..., 3, :, :] = np.clip(x[..., 3, :, :], 0.0, 1.0 + 1e-8)
+    return x
+
+
+def rollout_metrics(y_hat, y, mean=0.0, std=1.0, eps=1e-8, denorm=None):
+    """The validate_loop metric pair of train_stage2_ns2d.py:253-257 on [B,T,C,H,W] arrays; `denorm` replaces the
+    scalar affine map by another dataset's denormalize (a callable applied to both arrays)."""
+    if denorm is None:
+        yh, yt = denormalize(y_hat, mean, std), denormalize(y, mean, std)
+    else:
+        yh, yt = denorm(y_hat), denorm(y)
     return relative_lp_loss(yh, yt, (3, 4), eps), relative_lp_loss(yh, yt, (1, 3, 4), eps)
+
+
+def smooth_l1_loss(pred, target, beta=1.0):
+    """torch.nn.functional.smooth_l1_loss (mean reduction), the loss_fn of train_stage2_ns2d.py:209,227."""
+    d = np.abs(np.asarray(pred, np.float64) - np.asarray(target, np.float64))
+    return float(np.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta).mean())
+
+
+def teacher_forced_loss(dyn, z_in, z_out, param=None, loss_fn=smooth_l1_loss):
+    """LatentDynamics.forward (train_stage2_ns2d.py:126-141): roll the propagator t_out steps from z_in[:, 0] and
+    compare the stacked latents with z_out.  dyn: OracleDynamics."""
+    z = np.asarray(z_in)[:, 0]
+    preds = []
+    for _ in range(z_out.shape[1]):
+        z = dyn.prop.forward(z, param)
+        preds.append(z)
+    return loss_fn(np.stack(preds, 1), z_out)
 
 
 def encode_dataset(ae, frames, chunk=32, mean=0.0, std=1.0):

@@ -54,3 +54,28 @@ def synthetic_state_dict(shapes, seed):
         if k.endswith("inv_freq"):
             sd[k] = inv_freq(2 * int(shp[0]))
     return sd
+
+
+# ---- denormalise + relative-L2 metric fixtures (tests/golden/metrics.npz, tools/make_golden_metrics.py)
+METRIC_SEED = 11
+METRIC_STATS = {
+    "ns2d": dict(shape=(2, 5, 3, 32, 32), mean=0.37, std=1.9),
+    "sw": dict(shape=(2, 4, 3, 24, 48), mean=[0.4, -0.2, 9.5], std=[2.1, 1.7, 0.6]),
+    "twophase": dict(shape=(2, 4, 4, 31, 61), vel_mean=0.013, vel_std=0.21, prs_mean=310.0, prs_std=180.0),
+}
+
+
+def metric_inputs(name):
+    """Deterministic (torch-RNG-independent) synthetic pair: truth y ~ N(0,1), prediction y + 0.05 N(0,1).
+    The two-phase VOF channel is spread over about (-0.5, 1.5) so that the clamp acts on both sides; one NS2d plane
+    of the truth denormalises to ~0 (the eps clamp of relative_lp_loss)."""
+    from lns_amd import filler
+    shape = METRIC_STATS[name]["shape"]
+    y = filler.normal("metric_y_" + name, shape, METRIC_SEED)
+    yh = (y + 0.05 * filler.normal("metric_e_" + name, shape, METRIC_SEED)).astype(np.float32)
+    if name == "twophase":
+        y[:, :, 3] = 0.5 + 0.35 * y[:, :, 3]
+        yh[:, :, 3] = 0.5 + 0.35 * yh[:, :, 3]
+    if name == "ns2d":
+        y[0, 0, 0] = -METRIC_STATS[name]["mean"] / METRIC_STATS[name]["std"]
+    return yh.astype(np.float32), y.astype(np.float32)

@@ -75,6 +75,43 @@ def test_sharded_rollout_with_overlapped_gather_matches_unsharded():
     assert err == 0.0          # trajectories are independent: sharded == unsharded bit for bit
 
 
+def _metric_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lns_oracle
+    from helpers import METRIC_STATS, metric_inputs
+    from lns_amd import parallel
+    st = METRIC_STATS["ns2d"]
+    yh, y = metric_inputs("ns2d")                               # global batch of 2: one trajectory per rank
+    lo, hi = parallel.shard_bounds(yh.shape[0], rank, world)
+    f, s = lns_oracle.rollout_metrics(yh[lo:hi], y[lo:hi], st["mean"], st["std"])   # per-rank reduction (oracle on CPU)
+    f_all, s_all = parallel.gather_metrics(torch.from_numpy(f), torch.from_numpy(s))
+    if rank == 0:
+        f_ref, s_ref = lns_oracle.rollout_metrics(yh, y, st["mean"], st["std"])
+        q.put((tuple(f_all.shape), tuple(s_all.shape), bool((f_all.numpy() == f_ref).all()),
+               bool((s_all.numpy() == s_ref).all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_metrics_gather_only_the_reductions():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metric_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    fshape, sshape, f_ok, s_ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert fshape == (2, 5, 3) and sshape == (2, 3)
+    assert f_ok and s_ok       # per-trajectory reductions: sharded == unsharded
+
+
 def test_shard_bounds_cover_the_batch():
     from lns_amd import parallel
     for gb in (1, 7, 64, 512):

@@ -241,6 +241,58 @@ def test_metric_rel_l2_matches_oracle(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ns2d", "sw", "twophase"])
+def test_metric_matches_reference_golden(name):
+    """Fused denormalise + relative-L2 kernel (scalar stats; per-channel stats; closed-wall zeroing + VOF clamp)
+    against the real reference's dataset.denormalize + relative_lp_loss (tests/golden/metrics.npz)."""
+    _need_gpu()
+    import os
+    from helpers import GOLDEN, METRIC_STATS, metric_inputs
+    from lns_amd import metrics
+    g = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    st = METRIC_STATS[name]
+    yh, y = metric_inputs(name)
+    a, b = torch.from_numpy(yh).cuda(), torch.from_numpy(y).cuda()
+    if name == "twophase":
+        f, s = metrics.relative_l2(a, b, **metrics.twophase_spec(st["vel_mean"], st["vel_std"], st["prs_mean"], st["prs_std"]))
+    else:
+        f, s = metrics.relative_l2(a, b, st["mean"], st["std"])
+    f, s = f.cpu().numpy().astype(np.float64), s.cpu().numpy().astype(np.float64)
+    f_ref, s_ref = g[name + "_frame_f64"], g[name + "_seq_f64"]
+    big = f_ref > 1e3                            # eps-clamp-dominated entries
+    assert np.allclose(f[~big], f_ref[~big], rtol=2e-5, atol=1e-7)
+    assert np.allclose(np.log(f[big]), np.log(f_ref[big]), rtol=1e-2) if big.any() else True
+    assert np.allclose(s, s_ref, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["ns2d_mini", "twophase_cond"])
+def test_teacher_forced_loss_matches_oracle(preset):
+    """LatentDynamics.forward(z_in, z_out[, param], loss_fn): loss value of the latent rollout against pre-encoded
+    targets (train_stage2_ns2d.py:126-141), vs the oracle; with autograd enabled it must raise (no backward)."""
+    _need_gpu()
+    import gpu_checks as gc
+    import lns_oracle
+    import torch.nn.functional as F
+    from lns_amd import config, filler
+    args = config.preset(preset)
+    model, orc = gc.build_models(args, 1)
+    B, T = 2, 4
+    c, h, w = model._engine(torch.zeros(1, device="cuda")).latent_shape()
+    z_in = filler.normal("tf_zin", (B, 1, c, h, w), 5).astype(np.float32) * 0.5
+    z_out = filler.normal("tf_zout", (B, T, c, h, w), 6).astype(np.float32) * 0.5
+    param = filler.uniform01("tf_param", B, 5).astype(np.float32) if args.family == "twophase_cond" else None
+    ref = lns_oracle.teacher_forced_loss(orc, z_in, z_out, param)
+    zi, zo = torch.from_numpy(z_in).cuda(), torch.from_numpy(z_out).cuda()
+    extra = (torch.from_numpy(param).cuda(),) if param is not None else ()
+    with torch.no_grad():
+        loss = model(zi, zo, *extra, F.smooth_l1_loss)
+    assert abs(float(loss) - ref) <= 2e-5 * abs(ref), (float(loss), ref)
+    with pytest.raises(NotImplementedError):
+        model(zi, zo, *extra, F.smooth_l1_loss)
+
+
+@pytest.mark.gpu
 def test_encode_dataset_matches_oracle():
     """Bulk pre-encoding (chunks of frames through the encoder, dataset normalisation applied first)."""
     _need_gpu()

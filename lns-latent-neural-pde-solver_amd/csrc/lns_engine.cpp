@@ -262,6 +262,17 @@ struct Planner {
     Arena arena;
     Planner(lns_engine* e_, Plan* p, int B_) : e(e_), plan(p), B(B_) {}
 
+    // Scratch for GroupNorm partials written by convolution epilogues: allocated before any op so that it never
+    // aliases a tensor (the producing conv writes it while its own inputs are still being read).
+    uint64_t stat_scratch = 0;
+    size_t stat_cap = 0;
+    void init_stat_scratch() {
+        static const bool off = getenv("LNS_GN_NO_FUSE") != nullptr;
+        if (off) return;
+        stat_cap = (size_t)B * 128 * e->cfg.Ly * e->cfg.Lx / GN_TILE_PIXELS * 8;   // C * H * W <= 128 * Ly * Lx
+        stat_scratch = tag(SP_WS, arena.alloc(stat_cap));
+    }
+
     uint64_t wt(size_t float_off) const { return tag(SP_WT, float_off * 4); }
     uint64_t vecp(int id) const { return id < 0 ? 0 : wt(e->vecs[id].off); }
     int vec_id(const std::string& key) const {
@@ -314,6 +325,28 @@ struct Planner {
         x.ss = tag(SP_WS, x.ss_off); x.ss_owned = true;
         op.gn.ss = as_ptr<float>(x.ss); op.gn.B = B;
         op.bytes = 2.0 * B * x.C * x.H * x.W * 4;
+        // Fed by the 3x3 split-operand kernel right before it (nothing in between but traces), 128-pixel tiles
+        // covering the plane exactly: the conv epilogue leaves per-tile (mean, M2) and this op only merges them.
+        // Layer-static decision, so results do not depend on the batch.
+        static const long min_hw = getenv("LNS_GN_FUSE_MIN_HW") ? atol(getenv("LNS_GN_FUSE_MIN_HW")) : 1024;
+        Op* prod = nullptr;
+        for (size_t i = plan->ops.size(); i-- > 0;) {
+            if (plan->ops[i].type == OP_TRACE) continue;
+            prod = &plan->ops[i];
+            break;
+        }
+        if (stat_scratch && !premul && prod && prod->type == OP_CONV && (prod->variant == CV_F64 || prod->variant == CV_B64) &&
+            prod->conv.y == as_ptr<float>(x.ptr) && prod->conv.Cout == x.C && (long)x.H * x.W >= min_hw) {
+            const ConvArgs& c = prod->conv;
+            const int BW = 1 << c.bw_log2, BH = GN_TILE_PIXELS / BW;
+            const int tiles = c.tiles_x * c.tiles_y;
+            if (c.tiles_x * BW == x.W && c.tiles_y * BH == x.H && (size_t)B * tiles * x.C * 8 <= stat_cap) {
+                prod->conv.stat_part = as_ptr<float>(stat_scratch);
+                op.gn_tile_part = as_ptr<const float>(stat_scratch);
+                op.gn_tiles = tiles;
+                op.bytes = 2.0 * B * tiles * x.C * 8;
+            }
+        }
         plan->ops.push_back(op);
     }
 
@@ -909,6 +942,7 @@ static int get_plan(lns_engine* e, PlanKind kind, int B, int H, int W, Plan** ou
     plan.B = B; plan.H = H; plan.W = W;
     try {
         Planner pl(e, &plan, B);
+        pl.init_stat_scratch();
         if (kind == PK_ENC) {
             if (e->enc.empty()) throw std::runtime_error("engine has no autoencoder");
             pl.lower_sequence(e->enc, ext_tensor(EX_IN, c.in_channels, c.Ly, c.Lx),
@@ -975,7 +1009,7 @@ struct Runner {
                 case OP_CONV: {
                     ConvArgs a = op.conv;
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
-                    fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B);
+                    fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B); fix(a.stat_part, B);
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
                     rc = launch_conv(op.variant, a, stream);
                     break;
@@ -983,6 +1017,12 @@ struct Runner {
                 case OP_GNSTATS: {
                     GnStatsArgs a = op.gn;
                     fix(a.x, B); fix(a.gamma, B); fix(a.beta, B); fix(a.premul, B); fix(a.ss, B); fixbs(a.x_bs, B);
+                    if (op.gn_tiles) {
+                        const float* tp = op.gn_tile_part;
+                        fix(tp, B);
+                        rc = launch_gn_tile_finalize(a, tp, op.gn_tiles, stream);
+                        break;
+                    }
                     rc = launch_gn_stats(a, a.ss + (size_t)a.B * a.C * 2, stream);
                     break;
                 }

@@ -81,6 +81,8 @@ struct Op {
     int variant = 0;
     ConvArgs conv;
     GnStatsArgs gn;
+    const float* gn_tile_part = nullptr;   // GroupNorm fed by a convolution's per-tile partials (tagged pointer)
+    int gn_tiles = 0;
     LnPeArgs ln;
     AttnArgs at;
     FaPoolArgs fp;

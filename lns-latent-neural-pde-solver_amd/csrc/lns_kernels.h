@@ -45,6 +45,10 @@ struct ConvArgs {
     const void* wb;
     float unscale;         // accumulator scale of the bf16x3 / f16x2 epilogue: 1, or 1 / (16 * weight scale) for the fp16 form
     int ct_per_block;      // 1x1 bf16x3, input-stationary form: cout tiles walked by one block (0 = streaming form)
+    // 3x3 split-operand kernel, 128-pixel tiles that cover the plane exactly: per (sample, pixel tile, channel)
+    // (mean, centred second moment) of the stored output, [B][tiles][Cout][2]; the following GroupNorm merges them
+    // (launch_gn_tile_finalize) instead of reading the tensor again.  Null: not requested.
+    float* stat_part;
     int B;
 };
 
@@ -98,6 +102,9 @@ struct GnStatsArgs {
 // part: [B][C][2] scratch enabling the two-stage path (may be null)
 bool gn_stats_two_stage(const GnStatsArgs& a);
 hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s);
+// GroupNorm scale/shift from the per-tile partials a convolution epilogue left (ConvArgs::stat_part); a.x unused
+#define GN_TILE_PIXELS 128
+hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, hipStream_t s);
 
 // LayerNorm over channels of a channel-major token tensor + positional embedding
 struct LnPeArgs {

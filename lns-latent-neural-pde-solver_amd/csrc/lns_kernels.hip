@@ -706,6 +706,13 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     acc[m2][nt][r] = (a2h[m2][r] + a2l[m2][r]) * unscale2 + b2s[m2 * 32 + drow(r, kh)];
         }
     }
+    // GroupNorm statistics of the stored tile (planner: only when the 128-pixel tiles cover the plane exactly, so
+    // every pixel of the tile is valid): the tile goes through LDS as [channel][pixel], four threads per channel
+    // take 32 pixels each (two-pass mean / centred second moment in registers) and merge pairwise (Chan et al.).
+    constexpr int SROW = 133;                                    // 128 pixels + one pad word per 32 + 1
+    const bool stats = NT == 1 && MT == 2 && a.stat_part != nullptr;     // block-uniform
+    float* sb = reinterpret_cast<float*>(lds);
+    if (stats) __syncthreads();                                  // main-loop / fused-conv LDS reads are done
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if (pix[nt] < 0) continue;
@@ -721,8 +728,44 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     float v = acc[mt][nt][r];
                     if (rb) v += rb[(long)cob * HWo + pix[nt] + ro];
                     yp[ro] = v;
+                    if (stats) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;
                 }
             }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        const int c = tid >> 2, q = tid & 3;
+        const float* row = sb + c * SROW + q * 33;
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = row[i];
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
+        float mean = ((s0 + s1) + (s2 + s3)) * (1.0f / 32.0f);
+        float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) {
+            const float d0 = v[i] - mean, d1 = v[i + 1] - mean, d2 = v[i + 2] - mean, d3 = v[i + 3] - mean;
+            q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+        }
+        float m2 = (q0 + q1) + (q2 + q3);
+        {   // 32 + 32 pixels, then 64 + 64
+            const float mo = __shfl_xor(mean, 1), qo = __shfl_xor(m2, 1), d = mean - mo;
+            m2 = (m2 + qo) + d * d * 16.0f;
+            mean = 0.5f * (mean + mo);
+        }
+        {
+            const float mo = __shfl_xor(mean, 2), qo = __shfl_xor(m2, 2), d = mean - mo;
+            m2 = (m2 + qo) + d * d * 32.0f;
+            mean = 0.5f * (mean + mo);
+        }
+        const int co = ct * TM + c;
+        if (q == 0 && co < a.Cout) {
+            const int tile = blockIdx.x / a.cout_tiles, ntiles = a.tiles_x * a.tiles_y;
+            float* pp = a.stat_part + (((long)b * ntiles + tile) * a.Cout + co) * 2;
+            pp[0] = mean; pp[1] = m2;
         }
     }
 }
@@ -1895,6 +1938,43 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnStatsArgs a, const fl
         a.ss[((long)b * a.C + ch) * 2] = rstd * ga * p;
         a.ss[((long)b * a.C + ch) * 2 + 1] = be - mean * rstd * ga;
     }
+}
+
+// GroupNorm scale/shift from the per-tile (mean, M2) partials a convolution epilogue left: [B][tiles][C][2], every
+// partial over GN_TILE_PIXELS values.  One block per (group, sample); fixed order, exact merge of equal-count sets.
+__global__ __launch_bounds__(256) void gn_tile_finalize_kernel(GnStatsArgs a, const float* part, int tiles) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cg = a.C / a.groups;
+    const int E = tiles * cg;
+    const float* pb = part + (long)b * tiles * a.C * 2;
+    float sm = 0.0f;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const int t = i / cg, c = i - t * cg;
+        sm += pb[((long)t * a.C + g * cg + c) * 2];
+    }
+    const float mean = block_sum_256(sm, red) / (float)E;
+    float m2 = 0.0f;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const int t = i / cg, c = i - t * cg;
+        const float* pp = pb + ((long)t * a.C + g * cg + c) * 2;
+        const float d = pp[0] - mean;
+        m2 += pp[1] + (float)GN_TILE_PIXELS * d * d;
+    }
+    const float var = block_sum_256(m2, red) / ((float)GN_TILE_PIXELS * (float)E);
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    for (int c = threadIdx.x; c < cg; c += 256) {
+        const int ch = g * cg + c;
+        const float ga = a.gamma ? a.gamma[ch] : 1.0f;
+        const float be = a.beta ? a.beta[ch] : 0.0f;
+        a.ss[((long)b * a.C + ch) * 2] = rstd * ga;
+        a.ss[((long)b * a.C + ch) * 2 + 1] = be - mean * rstd * ga;
+    }
+}
+
+hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, hipStream_t s) {
+    hipLaunchKernelGGL(gn_tile_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a, tile_part, tiles);
+    return hipGetLastError();
 }
 
 bool gn_stats_two_stage(const GnStatsArgs& a) {

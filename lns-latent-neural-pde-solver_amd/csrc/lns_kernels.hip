@@ -25,6 +25,10 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {            // lane permutation inside every quad of lanes
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ int drow(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -751,13 +755,13 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
         }
         float m2 = (q0 + q1) + (q2 + q3);
-        {   // 32 + 32 pixels, then 64 + 64
-            const float mo = __shfl_xor(mean, 1), qo = __shfl_xor(m2, 1), d = mean - mo;
+        {   // 32 + 32 pixels, then 64 + 64 (lanes of one quad: DPP quad_perm, no LDS round trip)
+            const float mo = dpp_quad<0xB1>(mean), qo = dpp_quad<0xB1>(m2), d = mean - mo;      // [1,0,3,2]
             m2 = (m2 + qo) + d * d * 16.0f;
             mean = 0.5f * (mean + mo);
         }
         {
-            const float mo = __shfl_xor(mean, 2), qo = __shfl_xor(m2, 2), d = mean - mo;
+            const float mo = dpp_quad<0x4E>(mean), qo = dpp_quad<0x4E>(m2), d = mean - mo;      // [2,3,0,1]
             m2 = (m2 + qo) + d * d * 32.0f;
             mean = 0.5f * (mean + mo);
         }

@@ -47,6 +47,10 @@ def main():
         out["kernels"][cls] = {"kernel": n, "launches": launches, "fetch_bytes_per_launch": fetch,
                                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                                "fetch_x2_correction": x2}
+    # whole single-stream rollout (all kernels, raw counters, no x2 correction): where the HBM bytes go
+    out["rollout_total"] = {"fetch_bytes_raw": sum(f_tot.values()) * 1024.0, "write_bytes": sum(w_tot.values()) * 1024.0,
+                            "top_fetch_raw": {n.split("(")[0]: v * 1024.0 for n, v in sorted(f_tot.items(), key=lambda kv: -kv[1])[:8]},
+                            "top_write": {n.split("(")[0]: v * 1024.0 for n, v in sorted(w_tot.items(), key=lambda kv: -kv[1])[:8]}}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 

@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="trajectories per GPU")
     ap.add_argument("--rollout", type=int, default=64, help="latent rollout length T")
     ap.add_argument("--preset", default="ns2d_128")
-    ap.add_argument("--gather-chunk", type=int, default=16, help="step-block size of the overlapped all-gather")
+    ap.add_argument("--gather-chunk", type=int, default=8, help="step-block size of the overlapped all-gather")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK)")

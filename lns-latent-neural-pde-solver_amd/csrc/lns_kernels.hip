@@ -604,6 +604,24 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     const int HWo = a.Hout * a.Wout;
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+    // residual tile: all loads issued here, branch-free (clamped addresses), so their latency hides behind the
+    // epilogue arithmetic instead of one round trip per stored element (y may alias nothing, but the compiler
+    // cannot know and would not move a load above an earlier store)
+    float rv[MT][NT][16];
+    if (rb) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int cob = ct * TM + mt * 32 + 4 * kh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cob + (r & 3) + 8 * (r >> 2);
+                    const bool ok = pix[nt] >= 0 && co < a.Cout;
+                    rv[mt][nt][r] = rb[ok ? (long)co * HWo + pix[nt] : 0];      // elements that are not ok are never stored
+                }
+            }
+    }
     if (addv) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -730,7 +748,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 if (co < a.Cout) {
                     const int ro = ((r & 3) + 8 * (r >> 2)) * HWo;
                     float v = acc[mt][nt][r];
-                    if (rb) v += rb[(long)cob * HWo + pix[nt] + ro];
+                    if (rb) v += rv[mt][nt][r];
                     yp[ro] = v;
                     if (stats) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;
                 }

@@ -424,11 +424,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
             if (full_co) {
                 if (rb) {
                     const float* rp = rb + ((long)cob * HWo + pix);
+                    float rr[16];                              // all residual loads in flight before the first store
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ro = ((r & 3) + 8 * (r >> 2)) * HWo;
-                        yp[ro] = acc[mt][nt][r] + rp[ro];
-                    }
+                    for (int r = 0; r < 16; ++r) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * HWo];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yp[((r & 3) + 8 * (r >> 2)) * HWo] = acc[mt][nt][r] + rr[r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) yp[((r & 3) + 8 * (r >> 2)) * HWo] = acc[mt][nt][r];
@@ -632,20 +632,37 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
             }
     } else if (a.bias || a.badd) {
+        // all loads of one vector issued back to back (no per-element branch, one wait)
+        float add[MT][16];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int cob = ct * TM + mt * 32 + 4 * kh;
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cob + (r & 3) + 8 * (r >> 2);
-                const int cc = co < a.Cout ? co : 0;
-                float add = 0.0f;
-                if (a.bias) add += a.bias[cc];
-                if (a.badd) add += a.badd[(long)b * a.Cout + cc];
+            for (int r = 0; r < 16; ++r) add[mt][r] = 0.0f;
+        if (a.bias) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add;
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = ct * TM + mt * 32 + drow(r, kh);
+                    add[mt][r] = a.bias[co < a.Cout ? co : 0];
+                }
         }
+        if (a.badd) {
+            const float* bp = a.badd + (long)b * a.Cout;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = ct * TM + mt * 32 + drow(r, kh);
+                    add[mt][r] += bp[co < a.Cout ? co : 0];
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += add[mt][r];
     }
     if (a.act_out == ACT_GELU) {
 #pragma unroll
@@ -1739,12 +1756,13 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
         }
     }
     float* yb = a.y + (long)b * a.y_bs + (long)p4 * 4;
+    float bv[4];                                               // bias loads ahead of the stores
+#pragma unroll
+    for (int co = 0; co < 4; ++co) bv[co] = a.bias ? a.bias[co < CO ? co : 0] : 0.0f;
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
-        if (co < CO) {
-            const float bv = a.bias ? a.bias[co] : 0.0f;
-            *reinterpret_cast<float4*>(yb + (long)co * HW) = make_float4(acc[co][0] + bv, acc[co][1] + bv, acc[co][2] + bv, acc[co][3] + bv);
-        }
+        if (co < CO)
+            *reinterpret_cast<float4*>(yb + (long)co * HW) = make_float4(acc[co][0] + bv[co], acc[co][1] + bv[co], acc[co][2] + bv[co], acc[co][3] + bv[co]);
     }
 }
 
@@ -2391,11 +2409,17 @@ __device__ __forceinline__ void fa_reducer_mfma_body(const FaReducerArgs& a, int
         __syncthreads();
         for (int mt = wave; mt * 32 < oc; mt += 4) {
             const f32x16 acc = gemm_tile(Wt, 128, mt * 32, X2, Hid);
+            float b2v[16];                                 // bias loads batched ahead of the stores
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + mt * 32 + drow(r, kh);
+                b2v[r] = a.b2[o < Out ? o : 0];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + mt * 32 + drow(r, kh);
                 if (o < Out) {
-                    const float v = acc[r] + a.b2[o];
+                    const float v = acc[r] + b2v[r];
                     if (a.u && row < a.rows) a.u[(bi * Out + o) * a.n + ii] = v;
                     if (a.qk) X3[o * FARM_RP + l31] = v;
                 }
@@ -2493,26 +2517,31 @@ __device__ __forceinline__ void fa_lrk_body(const FaLrkArgs& a, char* smem) {
     const float* kb = qb + (long)a.heads * DK * n;
     const int tid = threadIdx.x;
     for (int base = 0; base < DK * npad; base += 256 * 8) {      // 8 elements (48 loads) in flight per thread
-        float qv[8], kv[8];
+        // branch-free loads (clamped indices) so that all 48 are issued before the first use
+        float c_[8], s_[8], q0[8], q1[8], k0[8], k1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + tid + u * 256;
             const int d = i / npad, j = i - d * npad;
-            qv[u] = 0.0f; kv[u] = 0.0f;
-            if (i < DK * npad && j < n) {
-                const int dm = d < half ? d : d - half;
-                const float cs = a.cs[((long)j * half + dm) * 2];
-                const float sn = a.cs[((long)j * half + dm) * 2 + 1];
-                const int dp = d < half ? d + half : d - half;
-                const float sg = d < half ? -1.0f : 1.0f;
-                qv[u] = qb[(long)d * n + j] * cs + sg * qb[(long)dp * n + j] * sn;
-                kv[u] = kb[(long)d * n + j] * cs + sg * kb[(long)dp * n + j] * sn;
-            }
+            const bool ok = i < DK * npad && j < n;
+            const int dd = ok ? d : 0, jj = ok ? j : 0;
+            const int dm = dd < half ? dd : dd - half;
+            const int dp = dd < half ? dd + half : dd - half;
+            const float2 t = *reinterpret_cast<const float2*>(a.cs + ((long)jj * half + dm) * 2);
+            c_[u] = t.x; s_[u] = t.y;
+            q0[u] = qb[(long)dd * n + jj]; q1[u] = qb[(long)dp * n + jj];
+            k0[u] = kb[(long)dd * n + jj]; k1[u] = kb[(long)dp * n + jj];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + tid + u * 256;
-            if (i < DK * npad) { qs[i] = qv[u]; ks[i] = kv[u]; }
+            const int d = i / npad, j = i - d * npad;
+            if (i < DK * npad) {
+                const bool ok = j < n;
+                const float sg = d < half ? -1.0f : 1.0f;
+                qs[i] = ok ? q0[u] * c_[u] + sg * q1[u] * s_[u] : 0.0f;
+                ks[i] = ok ? k0[u] * c_[u] + sg * k1[u] * s_[u] : 0.0f;
+            }
         }
     }
     __syncthreads();

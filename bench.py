@@ -139,13 +139,17 @@ def main():
     # each rank owns its own contiguous shard of the global batch (rank-dependent seed)
     x = torch.from_numpy(filler.normal("xbench-%d" % rank, (B, args.in_channels, args.Ly, args.Lx), 5)).to(dev)
     eng = model._engine(x)
+    # conditional two-phase preset: one normalised parameter per trajectory (U(0,1))
+    param = None
+    if getattr(args, "family", "") == "twophase_cond":
+        param = torch.from_numpy(filler.uniform01("pbench-%d" % rank, B, 5).astype("float32")).to(dev)
     C, H, W = eng.latent_shape()
     out = torch.empty((B, T, args.in_channels, args.Ly, args.Lx), dtype=torch.float32, device=dev)
     gather = world > 1 and not a.no_gather
     from lns_amd import parallel
 
     def _rollout_latent(z, steps, buf):
-        return eng.rollout_latent(z, steps, to_x=True, out=buf)[1]
+        return eng.rollout_latent(z, steps, param=param, to_x=True, out=buf)[1]
     chunked = None
     if gather:
         chunked = parallel.ChunkedGatherRollout(eng.encode, _rollout_latent, (args.in_channels, args.Ly, args.Lx),
@@ -153,7 +157,7 @@ def main():
 
     def one_pass():
         if chunked is None:
-            eng.rollout(x, T, to_x=True, out=out)
+            eng.rollout(x, T, param=param, to_x=True, out=out)
         else:
             # chunked rollout; each finished step block is all-gathered on a side stream
             chunked.run(x)
@@ -198,7 +202,7 @@ def main():
         # diagnostic pass single-stream, so kernel durations are not inflated by co-running
         # kernels; it is kept out of `value`'s timed region.
         eng.timing_enable(True)
-        eng.rollout(x, T, to_x=True, out=out)
+        eng.rollout(x, T, param=param, to_x=True, out=out)
         torch.cuda.synchronize()
         tm = eng.timing()
         eng.timing_enable(False)

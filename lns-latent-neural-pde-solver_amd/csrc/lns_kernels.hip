@@ -31,10 +31,20 @@ __device__ __forceinline__ float dpp_quad(float x) {            // lane permutat
 }
 __device__ __forceinline__ int drow(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
+// Sum over the 64 lanes, the same value in every lane.  Called by whole waves only.  Row (16-lane) sums through DPP
+// (quad permutes, half-row and row mirrors: register-file moves, no LDS crossbar round trips), then the four row sums
+// through v_readlane; fixed order.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_quad<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_quad<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_quad<0x141>(v);         // row_half_mirror
+    v += dpp_quad<0x140>(v);         // row_mirror
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // block-wide sum for blockDim.x == 256 (4 waves); red must hold >= 4 floats

@@ -660,6 +660,24 @@ struct Planner {
     // conditional propagator, step-invariant part: cond_emb_proj(fourier_embedding(param))
     // train_stage2_twophase_conditional.py:116, modules/cond_utils.py:19-38
     uint64_t cond_ce = 0; size_t cond_ce_off = 0; bool cond_ce_live = false;
+    // The embedding buffers (ce, and emb / mul of every block) depend on `param` only and are reused by the steps
+    // after the first one of a rollout: they come out of a pool taken from the arena BEFORE any op is lowered, so no
+    // tensor of the plan -- earlier or later -- can ever be placed on them.
+    size_t cond_pool_off = 0, cond_pool_cap = 0, cond_pool_used = 0;
+    void init_cond_pool() {
+        const lns_config& c = e->cfg;
+        if (c.cond_emb_dim <= 0 || c.prop_n_block <= 0) return;
+        cond_pool_cap = round_up_sz((size_t)B * c.cond_emb_dim * 4, 256) +
+                        (size_t)c.prop_n_block * 2 * round_up_sz((size_t)B * std::max(c.prop_n_embd, 1) * 4, 256);
+        cond_pool_off = arena.alloc(cond_pool_cap);
+    }
+    size_t cond_take(size_t bytes) {
+        bytes = round_up_sz(bytes, 256);
+        if (cond_pool_used + bytes > cond_pool_cap) throw std::runtime_error("conditional embedding pool exhausted");
+        const size_t off = cond_pool_off + cond_pool_used;
+        cond_pool_used += bytes;
+        return off;
+    }
     void emit_cond_base() {
         const lns_config& c = e->cfg;
         const int E = c.cond_emb_dim, half = E / 2;
@@ -674,7 +692,7 @@ struct Planner {
         op.cb.b0 = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.0.bias")));
         op.cb.w2_t = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.2.weight")));
         op.cb.b2 = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.2.bias")));
-        cond_ce_off = arena.alloc((size_t)B * E * 4);
+        cond_ce_off = cond_take((size_t)B * E * 4);
         cond_ce = tag(SP_WS, cond_ce_off); cond_ce_live = true;
         op.cb.ce = as_ptr<float>(cond_ce);
         plan->ops.push_back(op);
@@ -685,7 +703,7 @@ struct Planner {
         const lns_config& c = e->cfg;
         const int D = l.C, E = c.cond_emb_dim;
         const std::string q = l.name;
-        const size_t emb_off = arena.alloc((size_t)B * D * 4), mul_off = arena.alloc((size_t)B * D * 4);
+        const size_t emb_off = cond_take((size_t)B * D * 4), mul_off = cond_take((size_t)B * D * 4);
         {
             Op op;
             op.type = OP_CONDBLK; op.name = q + ".cond"; op.cls = CLS_COND;
@@ -718,7 +736,8 @@ struct Planner {
         free_t(xin2);
         TRef out = conv_same1(f1, l.p_f3, ACT_NONE, &x1, nullptr, q + ".ffn.3");
         free_t(f1); free_t(x1);
-        arena.release(emb_off); arena.release(mul_off);
+        // emb / mul (and cond_ce) are never released: they depend on `param` only, so the steps after the first one
+        // of a rollout reuse them (Runner::skip_step_invariant) and nothing else may be placed there
         return out;
     }
 
@@ -943,6 +962,7 @@ static int get_plan(lns_engine* e, PlanKind kind, int B, int H, int W, Plan** ou
     try {
         Planner pl(e, &plan, B);
         pl.init_stat_scratch();
+        if (kind == PK_PROP) pl.init_cond_pool();
         if (kind == PK_ENC) {
             if (e->enc.empty()) throw std::runtime_error("engine has no autoencoder");
             pl.lower_sequence(e->enc, ext_tensor(EX_IN, c.in_channels, c.Ly, c.Lx),
@@ -977,6 +997,9 @@ struct Runner {
     hipStream_t stream;
     std::vector<EvPair> evs;
     Runner(lns_engine* e_, hipStream_t s) : e(e_), stream(s) {}
+    // steps > 0 of a rollout: the conditional propagator's embedding MLPs depend on `param` only and their outputs
+    // live at fixed, never-reused arena offsets -- skip them
+    bool skip_step_invariant = false;
 
     int run(const Plan& plan, const ExtT* ext, char* arena_base) {
         Bases B;
@@ -989,6 +1012,7 @@ struct Runner {
             B.bs[SP_EXT0 + i] = ext[i].bs;
         }
         for (const Op& op : plan.ops) {
+            if (skip_step_invariant && (op.type == OP_CONDBASE || op.type == OP_CONDBLK)) continue;
             EvPair ev;
             if (e->timing_on && op.type != OP_TRACE) {
                 HIPCHK(e, hipEventCreate(&ev.a));
@@ -1384,7 +1408,10 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
             else { znext = {base + (size_t)slot * L.z_bytes, zper}; slot = slot % (ZRING - 1) + 1; }
             ext[EX_IN] = zcur;
             ext[EX_OUT] = znext;
-            if ((rc = r.run(*pp, ext, parena))) return rc;
+            r.skip_step_invariant = t > 0 && !e->trace_on;
+            rc = r.run(*pp, ext, parena);
+            r.skip_step_invariant = false;
+            if (rc) return rc;
             if (to_x) {
                 ext[EX_IN] = znext;
                 ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
@@ -1431,6 +1458,7 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
         if (used[s]) HIPCHK(e, hipStreamWaitEvent(pstream, ev_free[s], 0));   // WAR: decode(t - (ZRING-1)) done
         ext[EX_IN] = zcur;
         ext[EX_OUT] = znext;
+        rp.skip_step_invariant = t > 0;
         if ((rc = rp.run(*pp, ext, parena))) return rc;
         HIPCHK(e, hipEventRecord(ev_z[s], pstream));
         const int d = t % ndec;

@@ -18,8 +18,18 @@ def shard_bounds(global_batch: int, rank: int, world: int):
 
 
 def chunk_lengths(T: int, chunk: int):
+    """Step-block schedule of the overlapped gather: long blocks first, `chunk`-step blocks last.  Every block
+    boundary drains the engine's stream pipeline (~0.8 ms on NS2d-128, tools/chunk_cost.py) and the gather of the LAST
+    block is the only exposed one, so the blocks halve (T/2, T/4, ...) down to `chunk`: 64 steps, chunk 8 ->
+    [32, 16, 8, 8]."""
     chunk = max(1, min(chunk, T))
-    return [min(chunk, T - i) for i in range(0, T, chunk)]
+    lens, rem = [], T
+    while rem >= 4 * chunk:
+        take = (rem // 2) // chunk * chunk
+        lens.append(take)
+        rem -= take
+    lens += [min(chunk, rem - i) for i in range(0, rem, chunk)]
+    return lens
 
 
 class ChunkedGatherRollout:

@@ -64,14 +64,14 @@ def test_sharded_rollout_with_overlapped_gather_matches_unsharded():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, 2, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 9, 2, q)) for r in range(2)]   # blocks [4, 2, 2, 1]
     for p in procs:
         p.start()
     shape, err = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert shape == (4, 5, 2, 32, 32)
+    assert shape == (4, 9, 2, 32, 32)
     assert err == 0.0          # trajectories are independent: sharded == unsharded bit for bit
 
 
@@ -119,5 +119,8 @@ def test_shard_bounds_cover_the_batch():
             spans = [parallel.shard_bounds(gb, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == gb
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
-    assert parallel.chunk_lengths(64, 16) == [16, 16, 16, 16]
+    assert parallel.chunk_lengths(64, 16) == [32, 16, 16]
+    assert parallel.chunk_lengths(64, 8) == [32, 16, 8, 8]
+    assert parallel.chunk_lengths(256, 8) == [128, 64, 32, 16, 8, 8]
+    assert sum(parallel.chunk_lengths(37, 4)) == 37
     assert parallel.chunk_lengths(5, 2) == [2, 2, 1]

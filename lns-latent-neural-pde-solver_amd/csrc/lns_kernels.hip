@@ -2792,7 +2792,9 @@ __device__ __forceinline__ void split3_scalar(float x, unsigned short& h, unsign
     l = bf16_bits(r1 - __uint_as_float((unsigned)m << 16));
 }
 
-template <int HT, int WT, bool VEC>
+// FULL: H == 32 HT and W == 32 WT (the 32x32 and 64x64 planes of NS2d): the validity masks of the partial-tile form
+// drop out at compile time (same additions in the same order: both forms agree bit for bit on such planes).
+template <int HT, int WT, bool VEC, bool FULL = false>
 __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a, int planes_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HB = HT * 32, WB = WT * 32;
@@ -2993,7 +2995,7 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
                 for (int lt = 0; lt < WT; ++lt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const bool v = (it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W);
+                        const bool v = FULL || ((it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W));
                         sacc += v ? Yh[it][lt][r] : 0.0f;
                     }
             mean = wave_sum(sacc) * inv_cnt;
@@ -3004,7 +3006,7 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
                 for (int lt = 0; lt < WT; ++lt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const bool v = (it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W);
+                        const bool v = FULL || ((it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W));
                         const float d = Yh[it][lt][r] - mean;
                         q += v ? d * d : 0.0f;
                     }
@@ -3018,7 +3020,7 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = it * 32 + drow(r, kh), l = lt * 32 + l31;
-                    if (i < H && l < W) og[i * W + l] = (Yh[it][lt][r] - mean) * rstd;
+                    if (FULL || (i < H && l < W)) og[i * W + l] = (Yh[it][lt][r] - mean) * rstd;
                 }
     }
 }
@@ -3047,7 +3049,9 @@ static hipError_t launch_fa_sandwich_t(const FaSandwichArgs& a, hipStream_t s) {
         dim3 grid((a.C + ppb - 1) / ppb, a.heads, a.B);
         const size_t ldsb = fa_sandwich_b_lds_bytes(HT, WT);
         const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.u) & 15) == 0);
-        if (vec) hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true>), grid, dim3(256), ldsb, s, a, ppb);
+        if (vec && HT == WT && a.H == HT * 32 && a.W == WT * 32)       // layer-static: the shape decides, never the batch
+            hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true, (HT == WT)>), grid, dim3(256), ldsb, s, a, ppb);
+        else if (vec) hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true>), grid, dim3(256), ldsb, s, a, ppb);
         else hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, false>), grid, dim3(256), ldsb, s, a, ppb);
         return hipGetLastError();
     }
@@ -3447,6 +3451,8 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, true, 16>))
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, false, 16>))
     LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, true>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, true, true>))
+    LNS_SET_LDS((fa_sandwich_b_kernel<2, 2, true, true>))
     LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_b_kernel<1, 2, true>))
     LNS_SET_LDS((fa_sandwich_b_kernel<1, 2, false>))

@@ -2859,7 +2859,7 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
     auto prefetch = [&](const float* pg, int jt) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NQH; ++q) {
-            const bool ok = soff[q] >= 0 && (jt * 32 + soff[q] / W) < H;
+            const bool ok = FULL || (soff[q] >= 0 && (jt * 32 + soff[q] / W) < H);
             const int so = ok ? jt * 32 * W + soff[q] : 0;
             if (VEC) {
                 const float4 t = *reinterpret_cast<const float4*>(pg + so);
@@ -2894,8 +2894,8 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < NQH; ++q) {
-                const bool ok = soff[q] >= 0 && (jt * 32 + soff[q] / W) < H;
-                if (soff[q] >= 0) {
+                const bool ok = FULL || (soff[q] >= 0 && (jt * 32 + soff[q] / W) < H);
+                if (FULL || soff[q] >= 0) {
                     if (VEC) {
                         unsigned h0, m0, l0, h1, m1, l1;
                         split3_pair(ok ? pf[4 * q] : 0.0f, ok ? pf[4 * q + 1] : 0.0f, h0, m0, l0);

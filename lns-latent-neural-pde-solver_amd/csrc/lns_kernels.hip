@@ -2200,11 +2200,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mnew = fmaxf(m, tmax);
-        const float alpha = expf(m - mnew);
+        const float alpha = __builtin_amdgcn_exp2f((m - mnew) * 1.44269504088896341f);   // v_exp_f32, not the library expf
         float lt = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = expf(sacc[r] - mnew);
+            const float p = __builtin_amdgcn_exp2f((sacc[r] - mnew) * 1.44269504088896341f);
             sacc[r] = p;
             lt += p;
         }

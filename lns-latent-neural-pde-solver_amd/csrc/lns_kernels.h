@@ -57,7 +57,8 @@ enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4,
                    CV_B64 = 6 /* bf16x3 3x3 kernel */, CV_B1 = 7 /* bf16x3 1x1 kernel */,          // both 64 couts x 128 pixels
                    CV_B32 = 9 /* bf16x3 3x3 kernel, 32 couts x 128 pixels (same bits as CV_B64) */,
                    CV_F64 = 11 /* 3x3 kernel with the two-term fp16 split (f16x2), 64 couts x 128 pixels */,
-                   CV_THIN = 12 /* streaming 1x1 projection to <= 4 output channels (VALU, HBM-bound) */ };
+                   CV_THIN = 12 /* streaming 1x1 projection to <= 4 output channels (VALU, HBM-bound) */,
+                   CV_F32 = 13 /* f16x2 3x3 kernel, 32 couts x 128 pixels (same bits as CV_F64) */ };
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
 size_t conv_lds_bytes(int variant, const ConvArgs& a);

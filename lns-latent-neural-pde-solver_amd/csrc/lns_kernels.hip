@@ -484,7 +484,7 @@ static const ConvVariantInfo kConvInfo[CV_COUNT] = {
     {128, 256}, {64, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 128}};
 
 ConvVariantInfo conv_variant_info(int v) {
-    return v == CV_B32 ? ConvVariantInfo{32, 128} : v == CV_THIN ? ConvVariantInfo{32, 1024}
+    return (v == CV_B32 || v == CV_F32) ? ConvVariantInfo{32, 128} : v == CV_THIN ? ConvVariantInfo{32, 1024}
            : v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v];
 }
 
@@ -502,7 +502,8 @@ int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
 static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8 : CONV_MAXE3) : CONV_MAXE1; }
 
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
-    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return convb_lds_bytes(a, variant == CV_B32 ? 32 : 64, variant == CV_F64 ? 2 : 3);
+    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64 || variant == CV_F32)
+        return convb_lds_bytes(a, (variant == CV_B32 || variant == CV_F32) ? 32 : 64, (variant == CV_F64 || variant == CV_F32) ? 2 : 3);
     if (variant == CV_B1) return convb1_lds_bytes(a);
     if (variant == CV_THIN) return 0;
     const int KC = 1 << a.kc_log2;
@@ -513,7 +514,7 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 }
 
 bool conv_fits(int variant, const ConvArgs& a) {
-    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return convb_fits(a);
+    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64 || variant == CV_F32) return convb_fits(a);
     if (variant == CV_B1) return convb1_fits(a);
     if (variant == CV_THIN) return a.ks == 1 && a.stride == 1;   // pointer-dependent conditions are checked at launch
     const long KC = 1 << a.kc_log2;
@@ -547,7 +548,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 }
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
-    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64) return launch_conv_bf16x3(variant, a, s);
+    if (variant == CV_B64 || variant == CV_B32 || variant == CV_F64 || variant == CV_F32) return launch_conv_bf16x3(variant, a, s);
     if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
     if (variant == CV_THIN) return launch_conv1_thin(a, s);
     if (!conv_fits(variant, a)) return hipErrorInvalidValue;
@@ -1711,6 +1712,13 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
             if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 2, 2>), grid, dim3(256), lds, s, a);
             else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 2, 2>), grid, dim3(256), lds, s, a);
         }
+        return hipGetLastError();
+    }
+    if (variant == CV_F32) {                              // f16x2, 32-cout tiles: a.cout_tiles counts those
+        if (a.w2) return hipErrorInvalidValue;
+        const size_t lds = convb_lds_bytes(a, 32, 2);
+        if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 1, 2>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 1, 2>), grid, dim3(256), lds, s, a);
         return hipGetLastError();
     }
     if (variant == CV_B32) {                              // 32-cout tiles: a.cout_tiles counts those
@@ -3504,6 +3512,8 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 1>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 1, 2>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 1, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 1>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false>))

@@ -123,6 +123,7 @@ for _c in [dict(B=2, Cin=64, Cout=64, H=32, W=32, mode=(1, 1)), dict(B=2, Cin=64
     CONV_CASES.append(dict(k=3, variant=11, **_c))        # two-term fp16 split (f16x2) of the same kernel
     if not (_c.get('Cout') == 64 and _c.get('Cin') == 512):
         CONV_CASES.append(dict(k=3, variant=9, **_c))     # 32-cout tiles of the same kernel
+        CONV_CASES.append(dict(k=3, variant=13, **_c))    # f16x2 with 32-cout tiles
 # bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel
 # counts, prologue and epilogue features
 for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, Cout=128, H=16, W=16),

@@ -45,13 +45,19 @@ static size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 static inline uint64_t tag(int space, size_t byte_off) { return ((uint64_t)space << 56) | (uint64_t)byte_off; }
 template <class T> static inline T* as_ptr(uint64_t t) { return reinterpret_cast<T*>(t); }
 
-struct Bases { char* b[16]; long bs[16]; };
+struct Bases { char* b[16]; long bs[16]; mutable bool bad = false; };
 template <class T> static inline void fix(T*& p, const Bases& B) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     if (!v) return;
     const int sp = (int)(v >> 56);
+    if (sp == SP_NULL) return;                                                       // already a device address
+    if (sp >= 16 || !B.b[sp]) { B.bad = true; p = nullptr; return; }                 // tag without a base: never launch on it
     p = reinterpret_cast<T*>(B.b[sp] + (v & 0x00FFFFFFFFFFFFFFull));
 }
+// A planner-tagged pointer (space id in bits 56+) that reached a launch without fix() would be a wild device address
+// (the GPU abort of round 1, DESIGN.md "FUSE2 abort"): every pointer argument of an op is checked after resolution.
+static inline bool untagged(const void* p) { return (reinterpret_cast<uint64_t>(p) >> 56) == 0; }
+template <class... P> static inline bool all_untagged(P... ps) { return (untagged(ps) && ...); }
 static inline void fixbs(long& bs, const Bases& B) {
     if (bs < 0) bs = B.bs[SP_EXT0 + (int)(-bs - 1)];
 }
@@ -863,6 +869,14 @@ struct Planner {
 // ---------------------------------------------------------------------------
 // weights
 // ---------------------------------------------------------------------------
+static void release_overlap_objects(lns_engine* e) {
+    for (void* ev : e->events) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
+    e->events.clear();
+    if (e->side_stream) { (void)hipStreamDestroy(static_cast<hipStream_t>(e->side_stream)); e->side_stream = nullptr; }
+    for (hipStream_t st : e->dec_streams) (void)hipStreamDestroy(st);
+    e->dec_streams.clear();
+}
+
 static int finalize_weights(lns_engine* e, int device) {
     for (const Param& p : e->params)
         if (!p.is_set) { e->err = "weight not set: " + p.key; return LNS_ESTATE; }
@@ -923,6 +937,7 @@ static int finalize_weights(lns_engine* e, int device) {
     }
     HIPCHK(e, hipSetDevice(device));
     HIPCHK(e, init_kernels());
+    if (e->device >= 0 && e->device != device) release_overlap_objects(e);   // streams / events belong to the old device
     if (e->d_weights) { (void)hipFree(e->d_weights); e->d_weights = nullptr; }
     HIPCHK(e, hipMalloc(reinterpret_cast<void**>(&e->d_weights), std::max<size_t>(off, 64) * 4));
     HIPCHK(e, hipMemcpy(e->d_weights, host.data(), off * 4, hipMemcpyHostToDevice));
@@ -1028,7 +1043,8 @@ struct Runner {
                 HIPCHK(e, hipEventRecord(ev.a, stream));
             }
             hipError_t rc = hipSuccess;
-            // diagnostic (timing what-ifs only, results are garbage): LNS_SKIP_OPS=gn,fasmall
+#ifdef LNS_DIAG
+            // diagnostic build only (make DIAGFLAGS=-DLNS_DIAG; timing what-ifs, results are garbage): LNS_SKIP_OPS=gn,fasmall
             static const char* skip = getenv("LNS_SKIP_OPS");
             if (skip) {
                 const bool is_gn = op.type == OP_GNSTATS;
@@ -1036,12 +1052,15 @@ struct Runner {
                                     (op.type == OP_CONV && op.name.find("to_qk") != std::string::npos);
                 if ((is_gn && strstr(skip, "gn")) || (is_fas && strstr(skip, "fasmall"))) continue;
             }
+#endif
             switch (op.type) {
                 case OP_CONV: {
                     ConvArgs a = op.conv;
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
                     fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B); fix(a.stat_part, B);
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
+                    if (!all_untagged(a.x, a.w, a.bias, a.ss, a.rowmap, a.colmap, a.y, a.res, a.badd, a.w2, a.bias2, a.wb, a.stat_part)) B.bad = true;
+                    if (B.bad) break;
                     rc = launch_conv(op.variant, a, stream);
                     break;
                 }
@@ -1137,6 +1156,10 @@ struct Runner {
                     break;
                 }
                 default: e->err = "op not implemented: " + op.name; return LNS_EINVAL;
+            }
+            if (B.bad) {
+                e->err = fmt("internal error: unresolved pointer argument in %s (not launched)", op.name.c_str());
+                return LNS_EINVAL;
             }
             if (rc != hipSuccess) {
                 e->err = fmt("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(rc));
@@ -1269,9 +1292,7 @@ void lns_destroy(lns_engine* e) {
     for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans})
         for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
     if (e->d_weights) (void)hipFree(e->d_weights);
-    for (void* ev : e->events) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
-    if (e->side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(e->side_stream));
-    for (hipStream_t st : e->dec_streams) (void)hipStreamDestroy(st);
+    release_overlap_objects(e);
     delete e;
 }
 
@@ -1319,8 +1340,16 @@ int lns_latent_shape(const lns_engine* e, int* C, int* H, int* W) {
     return LNS_OK;
 }
 
+// the batch is a grid dimension (gridDim.y / .z) of every kernel
+#define LNS_MAX_BATCH 65535
+static int check_batch(lns_engine* e, int B) {
+    if (B > LNS_MAX_BATCH) { e->err = fmt("batch %d exceeds the maximum of %d trajectories per call", B, LNS_MAX_BATCH); return LNS_EINVAL; }
+    return LNS_OK;
+}
+
 int lns_prepare(lns_engine* e, int B, size_t* workspace_bytes) {
     if (!e || B <= 0) return LNS_EINVAL;
+    if (int brc = check_batch(e, B)) return brc;
     DeviceGuard dg(e);
     WsLayout L;
     int rc = ws_layout(e, B, &L);
@@ -1336,6 +1365,7 @@ static int check_ws(lns_engine* e, const WsLayout& L, void* ws, size_t bytes) {
 
 int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
     if (!e || !x || !z || B <= 0) return LNS_EINVAL;
+    if (int brc = check_batch(e, B)) return brc;
     DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
@@ -1352,6 +1382,7 @@ int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t 
 
 int lns_decode(lns_engine* e, const float* z, int B, float* y, void* ws, size_t ws_bytes, void* stream) {
     if (!e || !z || !y || B <= 0) return LNS_EINVAL;
+    if (int brc = check_batch(e, B)) return brc;
     DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
@@ -1369,6 +1400,7 @@ int lns_decode(lns_engine* e, const float* z, int B, float* y, void* ws, size_t 
 int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, int H, int W, float* z_out, void* ws,
                   size_t ws_bytes, void* stream) {
     if (!e || !z_in || !z_out || B <= 0 || H <= 0 || W <= 0) return LNS_EINVAL;
+    if (int brc = check_batch(e, B)) return brc;
     if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
     DeviceGuard dg(e);
     Plan* p; int rc;
@@ -1495,6 +1527,7 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
 int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T, int to_x, float* out,
                 float* latents_out, void* ws, size_t ws_bytes, void* stream) {
     if (!e || !x || !out || B <= 0 || T <= 0) return LNS_EINVAL;
+    if (int brc = check_batch(e, B)) return brc;
     if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
     if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
     DeviceGuard dg(e);
@@ -1520,6 +1553,7 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
 int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int B, int T, int to_x, float* out,
                        float* z_last, void* ws, size_t ws_bytes, void* stream) {
     if (!e || !z_in || !out || B <= 0 || T <= 0) return LNS_EINVAL;
+    if (int brc = check_batch(e, B)) return brc;
     if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
     if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
     DeviceGuard dg(e);

@@ -1,9 +1,16 @@
 // gfx950 (MI355X / CDNA4) kernels of the LNS rollout hot path.
 //
-// Numerics: everything is fp32 end to end.  The dense contractions run on the
-// exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (one rounding per
-// product, k-ordered fmaf chain), because the 1e-4 rel-L2 parity budget over a
-// 64-step autoregressive rollout excludes bf16/fp16.
+// Numerics: every tensor in HBM and every accumulator is fp32.  The dense contractions run on
+//   * v_mfma_f32_32x32x2_f32 (exact fp32 products, k-ordered fmaf chain): stride-2 / thin convolutions, attention,
+//     the small FABlock GEMMs, and every convolution when LNS_CONV_FP32_MFMA / LNS_CONV1_FP32_MFMA are set;
+//   * v_mfma_f32_32x32x16_f16 on SPLIT operands ("f16x2", the default for 3x3 stride-1 and 1x1 convolutions): each
+//     fp32 operand, scaled by a power of two, is the sum of two fp16 terms (22 significant bits + sign), the
+//     three kept partial products are exact in fp32 and accumulate in fp32.  The activation scale is chosen PER
+//     SAMPLE from the running absolute maximum its producer recorded (ConvArgs::amax_in), so the scheme has no
+//     fixed input range (see "dynamic activation scale" below);
+//   * v_mfma_f32_32x32x16_bf16 on three-term bf16 splits ("bf16x3", 24 bits, range of fp32): FABlock sandwich
+//     and the 3x3 fallback (LNS_CONV3_SPLIT=bf16x3).
+// Plain bf16/fp16 products are excluded by the 1e-4 rel-L2 parity budget over 64+ autoregressive steps.
 //
 // 64-lane wavefront conventions used throughout:
 //   l31 = lane & 31, kh = lane >> 5

@@ -91,6 +91,7 @@ class _Hosted(nn.Module):
         if owner is None:
             object.__setattr__(self, "_eng", _engine.Engine(cfg))
             object.__setattr__(self, "_sig", None)
+            object.__setattr__(self, "_flat", None)
 
     @property
     def _owner(self):
@@ -103,11 +104,17 @@ class _Hosted(nn.Module):
             raise LnsError("the LNS drop-in runs on HIP device tensors only (input is on %s); there is "
                            "no CPU fallback -- use the reference implementation on CPU"
                            % (getattr(like, "device", "host")))
-        sd = own.state_dict()
+        # The tensors of the parameter tree are looked up ONCE (the tree is fixed after construction; load_state_dict,
+        # .to(), in-place updates keep the Parameter objects and change their storage / version counter); a call only
+        # compares (storage pointer, version) of each and re-packs the weights when something changed.
+        flat = own._flat
+        if flat is None:
+            flat = [(k, t) for k, t in list(own.named_parameters()) + list(own.named_buffers())]
+            object.__setattr__(own, "_flat", flat)
         dev = like.device.index if like.device.index is not None else torch.cuda.current_device()
-        sig = (dev, tuple((t.data_ptr(), t._version) for t in sd.values()))
+        sig = (dev, tuple((t.data_ptr(), t._version) for _, t in flat))
         if own._sig != sig:
-            own._eng.load_weights({k: v.detach().to("cpu", torch.float32).numpy() for k, v in sd.items()}, dev)
+            own._eng.load_weights({k: t.detach().to("cpu", torch.float32).numpy() for k, t in flat}, dev)
             object.__setattr__(own, "_sig", sig)
         return own._eng
 

@@ -179,9 +179,23 @@ class Engine:
         return ws
 
     @staticmethod
-    def _stream():
+    def _stream(t):
+        """The current HIP stream of the device `t` lives on (not of whatever device is current)."""
         import torch
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def _param(self, param, like):
+        """Conditional propagator: one normalised parameter per trajectory -> fp32 [B] on like's device."""
+        import torch
+        if param is None:
+            return None
+        B = like.shape[0]
+        p = torch.as_tensor(param)
+        if p.numel() != B:
+            raise LnsError("param must hold one value per trajectory: got %d values for batch %d" % (p.numel(), B))
+        if p.device != like.device:
+            raise LnsError("param is on %s but the fields are on %s" % (p.device, like.device))
+        return p.reshape(B).to(torch.float32).contiguous()
 
     @staticmethod
     def _dev(t):
@@ -201,7 +215,7 @@ class Engine:
         z = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         ws = self._workspace(B, x.device)
         self._check(self._L.lns_encode(self._h, x.data_ptr(), B, z.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       self._stream()), "lns_encode")
+                                       self._stream(x)), "lns_encode")
         return z
 
     def decode(self, z):
@@ -212,7 +226,7 @@ class Engine:
         y = torch.empty((B, c.in_channels, c.Ly, c.Lx), dtype=torch.float32, device=z.device)
         ws = self._workspace(B, z.device)
         self._check(self._L.lns_decode(self._h, z.data_ptr(), B, y.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       self._stream()), "lns_decode")
+                                       self._stream(z)), "lns_decode")
         return y
 
     def propagate(self, z, param=None):
@@ -220,12 +234,12 @@ class Engine:
         z = self._dev(z)
         B, C, H, W = z.shape
         out = torch.empty_like(z)
-        p = self._dev(param.to(torch.float32)) if param is not None else None
+        p = self._param(param, z)
         # propagator-only engines have no lns_prepare(): size generously from the activations
         ws = self._workspace(B, z.device, min_bytes=64 * B * max(C, self.cfg.prop_n_embd) * H * W * 4 + (1 << 22))
         self._check(self._L.lns_propagate(self._h, z.data_ptr(), p.data_ptr() if p is not None else None,
                                           B, H, W, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          self._stream()), "lns_propagate")
+                                          self._stream(z)), "lns_propagate")
         return out
 
     def rollout(self, x, steps, param=None, to_x=True, return_latents=False, out=None):
@@ -240,12 +254,12 @@ class Engine:
         elif tuple(out.shape) != shape or not out.is_contiguous():
             raise LnsError("preallocated output must be contiguous with shape %s" % (shape,))
         lat = torch.empty((B, steps, C, H, W), dtype=torch.float32, device=x.device) if return_latents else None
-        p = self._dev(param.to(torch.float32)) if param is not None else None
+        p = self._param(param, x)
         ws = self._workspace(B, x.device)
         self._check(self._L.lns_rollout(self._h, x.data_ptr(), p.data_ptr() if p is not None else None, B,
                                         int(steps), int(bool(to_x)), out.data_ptr(),
                                         lat.data_ptr() if lat is not None else None, ws.data_ptr(),
-                                        ws.numel(), self._stream()), "lns_rollout")
+                                        ws.numel(), self._stream(x)), "lns_rollout")
         return (out, lat) if return_latents else out
 
     def rollout_latent(self, z, steps, param=None, to_x=True, out=None):
@@ -261,11 +275,11 @@ class Engine:
         elif tuple(out.shape) != shape or not out.is_contiguous():
             raise LnsError("preallocated output must be contiguous with shape %s" % (shape,))
         z_last = torch.empty_like(z)
-        p = self._dev(param.to(torch.float32)) if param is not None else None
+        p = self._param(param, z)
         ws = self._workspace(B, z.device)
         self._check(self._L.lns_rollout_latent(self._h, z.data_ptr(), p.data_ptr() if p is not None else None, B,
                                                int(steps), int(bool(to_x)), out.data_ptr(), z_last.data_ptr(),
-                                               ws.data_ptr(), ws.numel(), self._stream()), "lns_rollout_latent")
+                                               ws.data_ptr(), ws.numel(), self._stream(z)), "lns_rollout_latent")
         return out, z_last
 
     # -- diagnostics ----------------------------------------------------------------

@@ -39,10 +39,23 @@ def relative_l2(y_hat, y, mean=0.0, std=1.0, eps=1e-8, zero_wall_channels=(), cl
     frame = torch.empty((B, T, C), dtype=torch.float32, device=y.device)
     seq = torch.empty((B, C), dtype=torch.float32, device=y.device)
     scratch = torch.empty((B * T * C * 2,), dtype=torch.float32, device=y.device)
+    if y_hat.device != y.device:
+        raise ValueError("y_hat is on %s but y is on %s" % (y_hat.device, y.device))
     L = _lib.lib()
     stream = ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
     per_channel = (not isinstance(mean, (int, float))) or (not isinstance(std, (int, float))) or \
         len(zero_wall_channels) > 0 or len(clamp_channels) > 0
+    # the metric entry points launch on the CURRENT device (include/lns.h): make that the tensors' device
+    with torch.cuda.device(y.device):
+        rc = _launch_metric(L, per_channel, y_hat, y, B, T, C, H, W, mean, std, eps, zero_wall_channels, clamp_channels,
+                            clamp, frame, seq, scratch, stream)
+    if rc != 0:
+        raise RuntimeError("lns_metric_rel_l2 failed (rc=%d)" % rc)
+    return frame, seq
+
+
+def _launch_metric(L, per_channel, y_hat, y, B, T, C, H, W, mean, std, eps, zero_wall_channels, clamp_channels, clamp,
+                   frame, seq, scratch, stream):
     if not per_channel:
         rc = L.lns_metric_rel_l2(y_hat.data_ptr(), y.data_ptr(), B, T, C, H * W, float(mean), float(std), float(eps),
                                  frame.data_ptr(), seq.data_ptr(), scratch.data_ptr(), stream)
@@ -61,9 +74,7 @@ def relative_l2(y_hat, y, mean=0.0, std=1.0, eps=1e-8, zero_wall_channels=(), cl
         rc = L.lns_metric_rel_l2_ch(y_hat.data_ptr(), y.data_ptr(), B, T, C, H, W, m, sd, fl, float(clamp[0]),
                                     float(clamp[1]), float(eps), frame.data_ptr(), seq.data_ptr(),
                                     scratch.data_ptr(), stream)
-    if rc != 0:
-        raise RuntimeError("lns_metric_rel_l2 failed (rc=%d)" % rc)
-    return frame, seq
+    return rc
 
 
 @torch.no_grad()

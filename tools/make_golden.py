@@ -45,6 +45,10 @@ CASES = {
     "sw_96x192x5": ("sw_96x192x5", {}, 2, 16, [1, 4, 16], 4),
     "twophase": ("twophase", {}, 2, 8, [1, 8], 3),
     "twophase_cond": ("twophase_cond", {}, 2, 16, [1, 4, 16], 3),
+    # long horizons of BASELINE configs 3, 4, 5 (T = 64 / 128 / 256): the per-horizon tolerance fixtures
+    "sw_96x192x5_T64": ("sw_96x192x5", {}, 2, 64, [16, 32, 64], 4),
+    "twophase_cond_T128": ("twophase_cond", {}, 2, 128, [16, 32, 64, 128], 3),
+    "ns2d_128_T256": ("ns2d_128", {}, 2, 256, [64, 128, 192, 256], 4),
 }
 WEIGHT_SEED = 1
 INPUT_SEED = 7

@@ -49,6 +49,7 @@ extern "C" {
 #define LNS_ESTATE (-3)     /* call order (weights not finalized, ...)   */
 #define LNS_ENOMEM (-4)     /* workspace too small / device alloc failed */
 #define LNS_EHIP (-5)       /* HIP runtime error                         */
+#define LNS_ENONFINITE (-6) /* lns_check_finite: a tensor of the last run holds inf / NaN */
 
 /* autoencoder flavour: which reference file the AE follows */
 #define LNS_AE_NONE 0
@@ -154,6 +155,15 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
 int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int B, int T, int to_x,
                        float* out, float* z_last, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Post-run health check.  Every kernel of a plan records, per sample, the running maximum of |y| of the tensor it
+ * produces (the side channel from which the split-operand convolutions derive their activation scale); a NaN or inf
+ * anywhere in a tensor survives in it.  This call synchronises `stream`, reads those few KB back from `workspace`
+ * (the one the last lns_encode / lns_decode / lns_propagate / lns_rollout* call for batch B used) and returns
+ * LNS_ENONFINITE with lns_last_error() naming the first layer (in execution order) and sample whose output was not
+ * finite -- or LNS_OK.  The reference has no equivalent (its fields would silently carry NaN); nothing on the hot
+ * path depends on it. */
+int lns_check_finite(lns_engine* e, int B, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- diagnostics -------------------------------------------------------- */
 /* Layer trace: when enabled the run calls synchronise after every reference
  * module boundary and keep a host copy of its output (tests compare them with
@@ -176,12 +186,15 @@ int lns_timing_info(const lns_engine* e, int index, char* name, int name_capacit
  *   y = act_out( conv(act_in(x * scale + shift)) + bias + badd ) + residual
  * x [B,Cin,Hin,Win] optionally nearest-resized to (Hv,Wv) before padding;
  * w [Cout,Cin,k,k] HOST pointer; ss [B,Cin,2] device (scale,shift) or NULL;
- * act: 0 none, 1 swish, 2 gelu.  tile_variant <0 = automatic. */
+ * act: 0 none, 1 swish, 2 gelu.  tile_variant <0 = automatic.
+ * amax_out (device, [B] unsigned, zero-initialised by the caller, or NULL): receives per sample the IEEE bit pattern of
+ * max |y| -- the side channel from which the split-operand (f16x2) kernels of a plan derive their per-sample
+ * power-of-two activation scale.  The entry point computes the same quantity for x itself before the launch. */
 int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv,
                   const float* w_host, const float* bias_host, int Cout, int ksize, int stride,
                   int dilation, int pad_t, int pad_b, int pad_l, int pad_r, int mode_y, int mode_x,
                   const float* ss, int act_in, int act_out, const float* residual,
-                  const float* badd, float* y, int tile_variant, void* stream);
+                  const float* badd, float* y, int tile_variant, void* stream, unsigned* amax_out);
 /* Diagnostic: runs two convolutions (GroupNorm+Swish prologue, circular padding, stride 1) repeatedly on two HIP
  * streams so that their workgroups share compute units, and counts output words that differ from what each
  * convolution produces alone.  variant_*: tile variant as in lns_op_conv2d (-1 automatic, 6 = bf16x3 3x3 kernel). */

@@ -259,6 +259,10 @@ struct TRef {
     uint64_t ss = 0; size_t ss_off = 0; bool ss_owned = false;
     int act = ACT_NONE;
     int vH = 0, vW = 0; float sch = 0, scw = 0;   // virtual nearest resize
+    // bound on |raw values| for the split-operand consumers: per-sample running maximum recorded by the producer
+    // (tagged pointer to [B] unsigned) or an analytic constant (LayerNorm / InstanceNorm outputs); neither: unknown
+    uint64_t amax = 0; float amax_const = 0.0f;
+    bool bounded() const { return amax != 0 || amax_const > 0.0f; }
     bool pending() const { return ss != 0 || act != ACT_NONE || vH != 0; }
 };
 
@@ -284,6 +288,25 @@ struct Planner {
         if (off) return;
         stat_cap = (size_t)B * 128 * e->cfg.Ly * e->cfg.Lx / GN_TILE_PIXELS * 8;   // C * H * W <= 128 * Ly * Lx
         stat_scratch = tag(SP_WS, arena.alloc(stat_cap));
+    }
+
+    // amax slots: one [B] unsigned vector per produced tensor, all in one region taken before any op (never aliased)
+    enum { AMAX_SLOTS = 768 };
+    size_t amax_off = 0; int amax_used = 0;
+    void init_amax_region() {
+        amax_off = arena.alloc((size_t)AMAX_SLOTS * B * 4);
+        plan->amax_off = amax_off;
+    }
+    uint64_t new_amax(const std::string& name) {
+        if (amax_used >= AMAX_SLOTS) throw std::runtime_error("amax slots exhausted at " + name);
+        plan->amax_names.push_back(name);
+        return tag(SP_WS, amax_off + (size_t)(amax_used++) * B * 4);
+    }
+    float vec_absmax(int id) const {
+        if (id < 0) return 0.0f;
+        float m = 0.0f;
+        for (float v : e->params[e->pindex.at(e->vecs[id].key)].host) m = std::max(m, fabsf(v));
+        return m;
     }
 
     uint64_t wt(size_t float_off) const { return tag(SP_WT, float_off * 4); }
@@ -371,15 +394,17 @@ struct Planner {
     }
     TRef emit_conv(const TRef& in, int pack_id, int k, int stride, int dil, const int* pad, int my, int mx,
                    int act_out, const TRef* res, uint64_t badd, const TRef* out_forced, const std::string& name,
-                   int fuse_pack = -1) {
+                   int fuse_pack = -1, bool want_amax = true) {
         const ConvPack& pk = e->packs[pack_id];
         if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
         const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
         ConvGeom g;
         const bool thin_ok = !res && !badd && act_out == ACT_NONE && fuse_pack < 0 && !in.vH &&
                              (in.act == ACT_NONE || (in.act == ACT_SWISH && in.ss != 0));
-        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0, pk.has_wb, pk.cin, pk.f16,
-                           thin_ok))
+        // split-operand kernels only where the input carries a bound for the dynamic activation scale (tensors
+        // handed in by the caller do not: those few convolutions stay on the fp32 matrix instruction)
+        if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0,
+                           pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok))
             throw std::runtime_error("no conv tiling for " + name);
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
@@ -423,7 +448,9 @@ struct Planner {
         if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
-        a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / ((g.variant == CV_B1 ? convb1_xscale() : CONVF_XSCALE) * pk.wscale) : 1.0f;
+        a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / pk.wscale : 1.0f;   // x 1/S in the kernel
+        a.amax_in = as_ptr<const unsigned>(in.amax); a.amax_in_const = in.amax_const;
+        if (want_amax) { out.amax = new_amax(name); out.amax_const = 0.0f; a.amax_out = as_ptr<unsigned>(out.amax); }
         a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.sel_kc_log2;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
@@ -448,9 +475,9 @@ struct Planner {
         return out;
     }
     TRef conv_same1(const TRef& in, int pack, int act_out, const TRef* res, const TRef* out_forced,
-                    const std::string& name, int fuse_pack = -1) {
+                    const std::string& name, int fuse_pack = -1, bool want_amax = true) {
         const int pad[4] = {0, 0, 0, 0};
-        return emit_conv(in, pack, 1, 1, 1, pad, 0, 0, act_out, res, 0, out_forced, name, fuse_pack);
+        return emit_conv(in, pack, 1, 1, 1, pad, 0, 0, act_out, res, 0, out_forced, name, fuse_pack, want_amax);
     }
     TRef conv_same3(const TRef& in, int pack, int dil, int my, int mx, int act_out, const TRef* res, uint64_t badd,
                     const std::string& name) {
@@ -482,6 +509,8 @@ struct Planner {
         const int n = x.H * x.W, inner = l.heads * l.dim_head;
         if (l.pe >= 0 && n > l.pe_len) throw std::runtime_error("SABlock: more tokens than positional table rows");
         TRef h = alloc_t(x.C, x.H, x.W);
+        // LayerNorm output: |(x - mean) rstd| <= sqrt(C - 1), so |h| <= sqrt(C) max|gamma| + max|beta| + max|pe|
+        h.amax_const = sqrtf((float)x.C) * vec_absmax(l.ln_g) + vec_absmax(l.ln_b) + vec_absmax(l.pe);
         {
             Op op;
             op.type = OP_LNPE; op.name = l.name + ".ln_pe"; op.cls = CLS_LNPE;
@@ -496,6 +525,7 @@ struct Planner {
         TRef qkv = conv_same1(h, l.qkv, ACT_NONE, nullptr, nullptr, l.name + ".qkv");
         free_t(h);
         TRef o = alloc_t(inner, x.H, x.W);
+        o.amax = qkv.amax;          // softmax rows are convex weights: |o| <= max |v| <= max |qkv| of the sample
         {
             Op op;
             op.type = OP_ATTN; op.name = l.name + ".attn"; op.cls = CLS_ATTN;
@@ -535,8 +565,10 @@ struct Planner {
         const int C = x.C, H = x.H, W = x.W, heads = l.heads, dh = l.dim_head, lat = l.fa_lat, DK = l.fa_dk;
         TRef xin = x; xin.owned = false;
         emit_gn(xin, 1, 1e-5f, l.fa_g, l.fa_b, 0, l.name + ".in_norm");
-        TRef uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj");
-        TRef v = conv_same1(xin, l.toin, ACT_NONE, nullptr, nullptr, l.name + ".to_in");
+        // (no amax for these two: their consumers -- sandwich on bf16x3, pooling -- need none, and the 512-plane
+        //  tensor is the largest of the path)
+        TRef uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj", -1, false);
+        TRef v = conv_same1(xin, l.toin, ACT_NONE, nullptr, nullptr, l.name + ".to_in", -1, false);
         free_t(xin);
         // axis pooling
         const size_t mx_off = arena.alloc((size_t)B * H * C * 4), my_off = arena.alloc((size_t)B * W * C * 4);
@@ -568,11 +600,13 @@ struct Planner {
         TRef qkx, qky;
         {
             TRef ux = alloc_t(lat, 1, H), uy = alloc_t(lat, 1, W);
+            ux.amax = new_amax(l.name + ".to_x"); uy.amax = new_amax(l.name + ".to_y");
             if (merge) {
                 Op op;
                 op.type = OP_FARED2; op.name = l.name + ".to_xy"; op.cls = CLS_FARED;
                 fill_reducer(op.fr, 0); fill_reducer(op.fr2, 1);
                 op.fr.u = as_ptr<float>(ux.ptr); op.fr2.u = as_ptr<float>(uy.ptr);
+                op.fr.amax_out = as_ptr<unsigned>(ux.amax); op.fr2.amax_out = as_ptr<unsigned>(uy.amax);
                 op.flops = 2.0 * B * (H + W) * ((double)C * C + 2.0 * C * C + 2.0 * C * lat);
                 plan->ops.push_back(op);
             } else {
@@ -581,6 +615,7 @@ struct Planner {
                     op.type = OP_FARED; op.name = l.name + (ax == 0 ? ".to_x" : ".to_y"); op.cls = CLS_FARED;
                     fill_reducer(op.fr, ax);
                     op.fr.u = as_ptr<float>((ax == 0 ? ux : uy).ptr);
+                    op.fr.amax_out = as_ptr<unsigned>((ax == 0 ? ux : uy).amax);
                     op.flops = 2.0 * B * (ax == 0 ? H : W) * ((double)C * C + 2.0 * C * C + 2.0 * C * lat);
                     plan->ops.push_back(op);
                 }
@@ -624,6 +659,8 @@ struct Planner {
             plan->ops.push_back(op);
         }
         arena.release(kx_off); arena.release(ky_off);
+        // InstanceNorm output (biased variance over H*W values): |y| <= sqrt(H*W - 1)
+        uphi.amax = 0; uphi.amax_const = sqrtf((float)(H * W));
         TRef out;
         if (can_fuse_1x1(e->packs[l.out1], e->packs[l.out3])) {
             // to_out.1 (512 -> 64, GELU) and to_out.3 (64 -> 64) + skip in ONE kernel
@@ -665,6 +702,7 @@ struct Planner {
         op.type = OP_APPLY; op.name = name; op.cls = CLS_MISC;
         op.ap.x = as_ptr<const float>(x.ptr); op.ap.x_bs = x.bs; op.ap.ss = as_ptr<const float>(x.ss);
         op.ap.act = act; op.ap.y = as_ptr<float>(y.ptr); op.ap.B = B; op.ap.C = x.C; op.ap.HW = x.H * x.W;
+        y.amax = new_amax(name); op.ap.amax_out = as_ptr<unsigned>(y.amax);
         op.bytes = 8.0 * B * x.C * x.H * x.W;
         plan->ops.push_back(op);
         return y;
@@ -784,6 +822,7 @@ struct Planner {
             op.fc.a = as_ptr<const float>(x1.ptr); op.fc.b = as_ptr<const float>(x2.ptr); op.fc.e = nullptr;
             op.fc.skip = as_ptr<const float>(x.ptr); op.fc.skip_bs = x.bs; op.fc.y = as_ptr<float>(out.ptr);
             op.fc.y_bs = out.bs; op.fc.B = B; op.fc.C = C; op.fc.HW = H * W;
+            out.amax = new_amax(l.name + ".combine"); out.amax_const = 0.0f; op.fc.amax_out = as_ptr<unsigned>(out.amax);
             plan->ops.push_back(op);
         }
         free_t(x1); free_t(x2);
@@ -863,6 +902,7 @@ struct Planner {
             if (op.type == OP_CONDBASE) rebase(op.cb.freqs);
         }
         plan->arena_bytes = arena.high;
+        plan->amax_bytes = (size_t)amax_used * B * 4;
     }
 };
 
@@ -897,7 +937,7 @@ static int finalize_weights(lns_engine* e, int device) {
     static const bool conv3_f16 = !(getenv("LNS_CONV3_SPLIT") && strcmp(getenv("LNS_CONV3_SPLIT"), "bf16x3") == 0);
     for (ConvPack& p : e->packs) {
         p.f16 = false; p.wscale = 1.0f;
-        const bool want = p.has_wb && ((p.k == 3 && conv3_f16) || (p.k == 1 && convb1_xscale() != 1.0f));
+        const bool want = p.has_wb && ((p.k == 3 && conv3_f16) || (p.k == 1 && convb1_is_f16()));
         if (!want) continue;
         float mx = 0.0f;
         for (const std::string& key : p.wkeys)
@@ -984,6 +1024,7 @@ static int get_plan(lns_engine* e, PlanKind kind, int B, int H, int W, Plan** ou
     try {
         Planner pl(e, &plan, B);
         pl.init_stat_scratch();
+        pl.init_amax_region();
         if (kind == PK_PROP) pl.init_cond_pool();
         if (kind == PK_ENC) {
             if (e->enc.empty()) throw std::runtime_error("engine has no autoencoder");
@@ -1033,6 +1074,8 @@ struct Runner {
             B.b[SP_EXT0 + i] = const_cast<char*>(static_cast<const char*>(ext[i].ptr));
             B.bs[SP_EXT0 + i] = ext[i].bs;
         }
+        // the amax side channel accumulates with atomic max: every run of the plan starts from zero
+        if (plan.amax_bytes) HIPCHK(e, hipMemsetAsync(arena_base + plan.amax_off, 0, plan.amax_bytes, stream));
         for (const Op& op : plan.ops) {
             if (skip_step_invariant && (op.type == OP_CONDBASE || op.type == OP_CONDBLK)) continue;
             EvPair ev;
@@ -1058,8 +1101,10 @@ struct Runner {
                     ConvArgs a = op.conv;
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
                     fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B); fix(a.stat_part, B);
+                    fix(a.amax_in, B); fix(a.amax_out, B);
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
-                    if (!all_untagged(a.x, a.w, a.bias, a.ss, a.rowmap, a.colmap, a.y, a.res, a.badd, a.w2, a.bias2, a.wb, a.stat_part)) B.bad = true;
+                    if (!all_untagged(a.x, a.w, a.bias, a.ss, a.rowmap, a.colmap, a.y, a.res, a.badd, a.w2, a.bias2, a.wb, a.stat_part,
+                                      a.amax_in, a.amax_out)) B.bad = true;
                     if (B.bad) break;
                     rc = launch_conv(op.variant, a, stream);
                     break;
@@ -1087,7 +1132,7 @@ struct Runner {
                 case OP_FARED: {
                     FaReducerArgs a = op.fr;
                     fix(a.m, B); fix(a.win_t, B); fix(a.ln_g, B); fix(a.ln_b, B); fix(a.w1_t, B); fix(a.w2_t, B);
-                    fix(a.b2, B); fix(a.u, B);
+                    fix(a.b2, B); fix(a.u, B); fix(a.amax_out, B);
                     rc = launch_fa_reducer(a, stream);
                     break;
                 }
@@ -1095,7 +1140,7 @@ struct Runner {
                     FaReducerArgs a[2] = {op.fr, op.fr2};
                     for (int i = 0; i < 2; ++i) {
                         fix(a[i].m, B); fix(a[i].win_t, B); fix(a[i].ln_g, B); fix(a[i].ln_b, B); fix(a[i].w1_t, B); fix(a[i].w2_t, B);
-                        fix(a[i].b2, B); fix(a[i].u, B); fix(a[i].wqk_t, B); fix(a[i].bqk, B); fix(a[i].qk, B);
+                        fix(a[i].b2, B); fix(a[i].u, B); fix(a[i].wqk_t, B); fix(a[i].bqk, B); fix(a[i].qk, B); fix(a[i].amax_out, B);
                     }
                     rc = launch_fa_reducer2(a[0], a[1], stream);
                     break;
@@ -1126,7 +1171,7 @@ struct Runner {
                     rc = launch_cond_block(a, stream);
                     break;
                 }
-                case OP_APPLY: { ApplyArgs a = op.ap; fix(a.x, B); fix(a.ss, B); fix(a.y, B); fixbs(a.x_bs, B); rc = launch_apply(a, stream); break; }
+                case OP_APPLY: { ApplyArgs a = op.ap; fix(a.x, B); fix(a.ss, B); fix(a.y, B); fix(a.amax_out, B); fixbs(a.x_bs, B); rc = launch_apply(a, stream); break; }
                 case OP_SPECTRAL: {
                     SpectralArgs a = op.sp;
                     fix(a.x, B); fix(a.w1, B); fix(a.w2, B); fix(a.emb, B); fix(a.t1, B); fix(a.xf, B); fix(a.of, B); fix(a.y, B);
@@ -1136,7 +1181,7 @@ struct Runner {
                 }
                 case OP_FCOMBINE: {
                     FourierCombineArgs a = op.fc;
-                    fix(a.a, B); fix(a.b, B); fix(a.e, B); fix(a.skip, B); fix(a.y, B); fixbs(a.skip_bs, B); fixbs(a.y_bs, B);
+                    fix(a.a, B); fix(a.b, B); fix(a.e, B); fix(a.skip, B); fix(a.y, B); fix(a.amax_out, B); fixbs(a.skip_bs, B); fixbs(a.y_bs, B);
                     rc = launch_fourier_combine(a, stream);
                     break;
                 }
@@ -1565,6 +1610,39 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
     return r.finish();
 }
 
+int lns_check_finite(lns_engine* e, int B, void* ws, size_t ws_bytes, void* stream) {
+    if (!e || B <= 0 || !ws) return LNS_EINVAL;
+    DeviceGuard dg(e);
+    HIPCHK(e, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    const bool full = !e->enc.empty();
+    WsLayout L;
+    int rc;
+    if (full && ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes)))) return rc;
+    char* base = static_cast<char*>(ws);
+    std::vector<unsigned> host;
+    auto scan = [&](const std::map<long, Plan>& plans, const char* what, char* arena) -> int {
+        for (const auto& kv : plans) {
+            const Plan& p = kv.second;
+            if (p.B != B || !p.amax_bytes) continue;
+            host.resize(p.amax_bytes / 4);
+            HIPCHK(e, hipMemcpy(host.data(), arena + p.amax_off, p.amax_bytes, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < p.amax_names.size(); ++i)
+                for (int b = 0; b < B; ++b)
+                    if (((host[i * B + b] >> 23) & 0xffu) == 0xffu) {
+                        e->err = fmt("non-finite values in the output of %s (%s, sample %d)", p.amax_names[i].c_str(), what, b);
+                        return LNS_ENONFINITE;
+                    }
+        }
+        return LNS_OK;
+    };
+    if (!full) return scan(e->prop_plans, "propagator", base);          // propagator-only engine: the arena is the workspace
+    if ((rc = scan(e->enc_plans, "encoder", base + L.arena_off))) return rc;
+    if ((rc = scan(e->prop_plans, "propagator", base + L.prop_off))) return rc;
+    for (int d = 0; d < L.ndec; ++d)
+        if ((rc = scan(e->dec_plans, "decoder", base + L.arena_off + (size_t)d * L.arena_stride))) return rc;
+    return LNS_OK;
+}
+
 // ---- diagnostics -------------------------------------------------------------
 int lns_trace_enable(lns_engine* e, int on) { if (!e) return LNS_EINVAL; e->trace_on = on != 0; e->trace.clear(); return LNS_OK; }
 int lns_trace_count(const lns_engine* e) { return e ? (int)e->trace.size() : LNS_EINVAL; }
@@ -1606,7 +1684,8 @@ struct OpConv {
     int variant = -1;
     float* dw = nullptr;
     int* dmaps = nullptr;
-    void release() { (void)hipFree(dw); (void)hipFree(dmaps); dw = nullptr; dmaps = nullptr; }
+    unsigned* damax = nullptr;     // [B] running max |x| of the input (dynamic activation scale of the split kernels)
+    void release() { (void)hipFree(dw); (void)hipFree(dmaps); (void)hipFree(damax); dw = nullptr; dmaps = nullptr; damax = nullptr; }
 };
 
 static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv,
@@ -1644,7 +1723,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
     if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
     float wscale = 1.0f;
-    if (g.variant == CV_F64 || g.variant == CV_F32 || (g.variant == CV_B1 && convb1_xscale() != 1.0f)) {
+    if (g.variant == CV_F64 || g.variant == CV_F32 || (g.variant == CV_B1 && convb1_is_f16())) {
         float mx = 0.0f;
         for (size_t i = 0; i < (size_t)Cout * Cin * ksize * ksize; ++i) mx = std::max(mx, fabsf(w_host[i]));
         if (mx > 0.0f) wscale = exp2f(floorf(log2f(16000.0f / mx)));
@@ -1672,7 +1751,13 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
-    a.unscale = (g.variant == CV_F64 || g.variant == CV_F32) ? 1.0f / (CONVF_XSCALE * wscale) : g.variant == CV_B1 ? 1.0f / (convb1_xscale() * wscale) : 1.0f;
+    a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / wscale : 1.0f;
+    // the input's per-sample maximum, as the producing kernel of a plan would have recorded it
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.damax), (size_t)B * 4));
+    OPCHK(hipMemset(oc.damax, 0, (size_t)B * 4));
+    OPCHK(launch_amax(x, a.x_bs, (long)Cin * Hin * Win, B, oc.damax, nullptr));
+    OPCHK(hipStreamSynchronize(nullptr));
+    a.amax_in = oc.damax;
     a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
     a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
@@ -1687,11 +1772,12 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
 int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv, const float* w_host,
                   const float* bias_host, int Cout, int ksize, int stride, int dilation, int pad_t, int pad_b, int pad_l,
                   int pad_r, int mode_y, int mode_x, const float* ss, int act_in, int act_out, const float* residual,
-                  const float* badd, float* y, int tile_variant, void* stream) {
+                  const float* badd, float* y, int tile_variant, void* stream, unsigned* amax_out) {
     OpConv oc;
     const int rc = op_conv_prepare(oc, x, B, Cin, Hin, Win, Hv, Wv, w_host, bias_host, Cout, ksize, stride, dilation, pad_t,
                                    pad_b, pad_l, pad_r, mode_y, mode_x, ss, act_in, act_out, residual, badd, y, tile_variant);
     if (rc) { oc.release(); return rc; }
+    oc.a.amax_out = amax_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
     OPCHK(launch_conv(oc.variant, oc.a, s));
     OPCHK(hipStreamSynchronize(s));
@@ -1886,10 +1972,10 @@ int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int
     sp.t1 = d + off[8]; sp.xf = d + off[9]; sp.of = d + off[10]; sp.y = d + off[11];
     OPCHK(launch_spectral(sp, s));
     int rc = lns_op_conv2d(x, B, C, H, W, H, W, conv_w_host, conv_b_host, C, 1, 1, 1, 0, 0, 0, 0, 0, 0, nullptr, 0, 0,
-                           nullptr, nullptr, d + off[12], -1, stream);
+                           nullptr, nullptr, d + off[12], -1, stream, nullptr);
     if (rc) { (void)hipFree(d); return rc; }
     FourierCombineArgs fc = {d + off[11], d + off[12], cond ? d + off[7] : nullptr, x, (long)C * H * W, y,
-                             (long)C * H * W, B, C, H * W};
+                             (long)C * H * W, B, C, H * W, nullptr};
     OPCHK(launch_fourier_combine(fc, s));
     OPCHK(hipStreamSynchronize(s));
     (void)hipFree(d);

@@ -105,6 +105,10 @@ struct Plan {
     void* d_consts = nullptr;         // device: ints then floats
     size_t arena_bytes = 0;
     int B = 0, H = 0, W = 0;
+    // amax side channel (dynamic activation scale of the split-operand convs): [slots][B] unsigned inside the arena,
+    // zeroed by one memset at the start of every run of the plan; slot i belongs to the tensor amax_names[i]
+    size_t amax_off = 0, amax_bytes = 0;
+    std::vector<std::string> amax_names;
 };
 
 struct ExtT { const void* ptr = nullptr; long bs = 0; };

@@ -50,7 +50,19 @@ struct ConvArgs {
     // (launch_gn_tile_finalize) instead of reading the tensor again.  Null: not requested.
     float* stat_part;
     int B;
+    // Dynamic activation scale of the split-operand (f16x2) kernels.  The producer of x recorded, per sample, the bit
+    // pattern of max |x| (amax_in, [B] unsigned; the maximum of IEEE bit patterns of non-negative floats is the maximum
+    // of the values, and a NaN anywhere survives as the largest pattern); when x is produced by a kernel with an
+    // analytic bound (LayerNorm, InstanceNorm) amax_in is null and amax_in_const holds the bound.  The kernel derives
+    // bound = max_c(|scale_c| amax + |shift_c|) (or amax without a prologue) and stages activations multiplied by the
+    // power of two S that puts `bound` in [2^14, 2^15): no fixed input range, fp16 never overflows, and the low term
+    // stays normal for every element within 2^-17 of the sample's maximum.
+    const unsigned* amax_in;
+    float amax_in_const;
+    unsigned* amax_out;    // [B] or null: atomic max of the bit patterns of |y| over everything this launch stores
 };
+// power-of-two activation scale from a bound on |x| (host mirror of the device rule; tests)
+float convf_scale_for_bound(float bound);
 
 // tile variants: (TM couts x TN pixels) per 256-thread block
 enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4, CV_S32 = 5, CV_COUNT = 6,
@@ -67,11 +79,10 @@ bool conv_fits(int variant, const ConvArgs& a);
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 // 3x3 convolution on bf16 MFMA with every fp32 operand split into three bf16 terms (6 products,
 // two accumulators): fp32-level accuracy at 2.7x the fp32-MFMA rate.  Tile 64 couts x 128 pixels.
-// f16x2 scheme: activations are multiplied by this power of two before the fp16 split.  Representable range
-// +-65504/16 = +-4094 (beyond: inf -> NaN results, loud); below 0.125/16 = 8e-3 the low term goes subnormal and the
-// absolute error per element is <= 2^-25/16 = 1.9e-9 (harmless unless a whole tensor is that small: a tensor of
-// N(0, 1e-3^2) values convolves with 1.1e-6 relative error instead of 1.7e-7).
-#define CONVF_XSCALE 16.0f
+// f16x2 scheme: activations are multiplied by a per-sample power of two before the fp16 split (ConvArgs::amax_in):
+// bound * S lies in [2^14, 2^15), the fp16 range (65504) is never reached and the absolute error of an element's
+// two-term representation is <= max(2^-22 |x|, 2^-39 bound).  S is clamped to [2^-100, 2^60].
+#define CONVF_TARGET_EXP 14
 #define CONVB_SLAB_BYTES 27648           // one (cout tile, stage) weight slab: 3 splits x 9 taps x 64 couts x 8 ch bf16
 size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits);
 bool convb_fits(const ConvArgs& a);
@@ -85,7 +96,7 @@ size_t convb1_lds_bytes(const ConvArgs& a);
 bool convb1_fits(const ConvArgs& a);
 size_t convb1_weight_bytes(int Cout, int Cin_pad);
 void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale);
-float convb1_xscale();   // factor the 1x1 kernels apply to activations before the split (power of two; 1 for bf16x3)
+bool convb1_is_f16();    // the 1x1 kernels use the two-term fp16 split (dynamic activation scale) rather than bf16x3
 hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s);
 bool conv1_thin_fits(const ConvArgs& a);
 hipError_t launch_conv1_thin(const ConvArgs& a, hipStream_t s);
@@ -135,6 +146,7 @@ struct FaReducerArgs {                 // PoolingReducer on pooled rows [rows, C
     const float* w2_t;                 // [Hid][Out]
     const float* b2;                   // [Out]
     float* u;                          // may be null when the to_qk projection below is fused
+    unsigned* amax_out;                // [B] or null: running max |u| per sample (consumer: the to_qk split-operand conv)
     // optional fused LowRankKernel.to_qk (1x1 conv Out -> Mqk on the reducer output): qk [B, Mqk, n]
     const float* wqk_t; int ldqk;      // in-major [Out][ldqk] (the conv's fp32 pack)
     const float* bqk;                  // [Mqk] or null
@@ -179,7 +191,7 @@ struct CondBlockArgs {           // emb = Wce ce + bce ; mul = 1 + conv1(gelu(co
 hipError_t launch_cond_block(const CondBlockArgs& a, hipStream_t s);
 
 // y = act(x * scale[b,c] + shift[b,c])  (materialises a pending GroupNorm + activation)
-struct ApplyArgs { const float* x; long x_bs; const float* ss; int act; float* y; int B, C, HW; };
+struct ApplyArgs { const float* x; long x_bs; const float* ss; int act; float* y; int B, C, HW; unsigned* amax_out; };
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t s);
 
 // Fourier blocks (opt-in): truncated DFT as dense contractions --------------------
@@ -197,7 +209,7 @@ struct SpectralArgs {
 hipError_t launch_spectral(const SpectralArgs& a, hipStream_t s);
 
 // y = skip + gelu(a + b + e[b,c])
-struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; long skip_bs; float* y; long y_bs; int B, C, HW; };
+struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; long skip_bs; float* y; long y_bs; int B, C, HW; unsigned* amax_out; };
 hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s);
 
 // out[b,o] = bias[o] + sum_i in[b,i] * w[i*ldo + o*ldi]   (tiny dense layer on per-sample vectors)
@@ -216,6 +228,9 @@ struct MetricChannelSpec {
 hipError_t launch_metric_rel_l2_ch(const float* yhat, const float* y, int B, int T, int C, int H, int W,
                                    const MetricChannelSpec& spec, float eps, float* frame_out, float* seq_out,
                                    float* scratch, hipStream_t s);
+
+// per-sample max |x| (bit patterns) of a [B, n] tensor with batch stride x_bs: amax[b] = max(amax[b], ...)
+hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax, hipStream_t s);
 
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
 

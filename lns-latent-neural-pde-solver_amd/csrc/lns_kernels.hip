@@ -75,6 +75,62 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// ---------------------------------------------------------------------------
+// Dynamic activation scale of the f16x2 kernels ("amax side channel").
+// Every kernel that produces a tensor a split-operand convolution will read records, per sample, the maximum of the
+// IEEE bit patterns of |y| (unsigned max == float max for non-negative values; a NaN is the largest pattern and so
+// survives; atomicMax is exact and order-independent, so the result does not depend on block scheduling).  The
+// consumer turns the maximum -- pushed through its GroupNorm scale/shift prologue as max_c(|s_c| amax + |t_c|) -- into
+// a power-of-two scale S with S * bound in [2^14, 2^15).  Scaling by a power of two does not change the bits of the
+// fp16 high/low terms while they are normal numbers, so results do not depend on S in that regime.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+// max over the 64 lanes (bit patterns of non-negative floats), the same value in every lane; whole waves only
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, dpp_u<0xB1>(v));
+    v = max(v, dpp_u<0x4E>(v));
+    v = max(v, dpp_u<0x141>(v));
+    v = max(v, dpp_u<0x140>(v));
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+// one atomic per wave; called by whole waves
+__device__ __forceinline__ void amax_publish(unsigned* slot, unsigned local) {
+    const unsigned m = wave_umax(local);
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+}
+// S = 2^(CONVF_TARGET_EXP - e) for bound = m 2^e (1 <= m < 2), clamped to [2^-100, 2^60]; inv = 1 / S.
+// Non-finite bound (exponent field 255): S = 2^-100 and the staged values stay non-finite -> NaN results, as in fp32.
+__device__ __forceinline__ float f16x2_scale(unsigned bound_bits, float& inv) {
+    const int eb = (int)((bound_bits >> 23) & 0xffu);
+    int f = 127 + CONVF_TARGET_EXP + 127 - eb;
+    f = f < 27 ? 27 : (f > 187 ? 187 : f);
+    inv = __uint_as_float((unsigned)(254 - f) << 23);
+    return __uint_as_float((unsigned)f << 23);
+}
+// Block prologue shared by the split-operand kernels: stages this sample's GroupNorm (scale, shift) table into LDS
+// (identity for channels without one) and returns each wave's share of bound = max_c(|s_c| amax + |t_c|) through
+// wmax[wave] (4 words of LDS); after the block's next barrier block_bound() gives the block-wide value.
+__device__ __forceinline__ void stage_ss_bound(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid, int nthr) {
+    const bool has_ss = a.ss != nullptr;
+    const float amax = a.amax_in ? __uint_as_float(a.amax_in[b]) : a.amax_in_const;
+    unsigned loc = 0u;
+    for (int c = tid; c < a.Cin_pad; c += nthr) {
+        float2 st = make_float2(1.0f, 0.0f);
+        if (has_ss && c < a.Cin) st = *reinterpret_cast<const float2*>(a.ss + ((long)b * a.Cin + c) * 2);
+        *reinterpret_cast<float2*>(ssl + 2 * c) = st;
+        if (c < a.Cin) loc = max(loc, abs_bits(fmaf(fabsf(st.x), amax, fabsf(st.y))));
+    }
+    loc = wave_umax(loc);
+    if ((tid & 63) == 0) wmax[tid >> 6] = loc;
+}
+__device__ __forceinline__ unsigned block_bound(const unsigned* wmax) { return max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); }
+
 // block-wide sum for blockDim.x == 256 (4 waves); red must hold >= 4 floats
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);
@@ -446,6 +502,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     }
     // stores: row r of a tile is cout cob + (r&3) + 8*(r>>2); 128-byte pixel runs per half-wave.
     // Offsets from one per-(mt,nt) base pointer are multiples of HWo (uniform scalars).
+    unsigned am = 0u;                                  // bit pattern of max |stored value| (amax side channel)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
@@ -466,10 +523,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * HWo];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) yp[((r & 3) + 8 * (r >> 2)) * HWo] = acc[mt][nt][r] + rr[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[mt][nt][r] + rr[r];
+                        yp[((r & 3) + 8 * (r >> 2)) * HWo] = v;
+                        am = max(am, abs_bits(v));
+                    }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) yp[((r & 3) + 8 * (r >> 2)) * HWo] = acc[mt][nt][r];
+                    for (int r = 0; r < 16; ++r) {
+                        yp[((r & 3) + 8 * (r >> 2)) * HWo] = acc[mt][nt][r];
+                        am = max(am, abs_bits(acc[mt][nt][r]));
+                    }
                 }
             } else {
 #pragma unroll
@@ -480,11 +544,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
                         float v = acc[mt][nt][r];
                         if (rb) v += rb[(long)cob * HWo + pix + ro];
                         yp[ro] = v;
+                        am = max(am, abs_bits(v));
                     }
                 }
             }
         }
     }
+    if (a.amax_out) amax_publish(a.amax_out + b, am);
 }
 
 static const ConvVariantInfo kConvInfo[CV_COUNT] = {
@@ -630,7 +696,7 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 template <int NT, bool FUSE2, int MT = 2>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
-                                               const float* addv = nullptr) {
+                                               float unscale, const float* addv = nullptr) {
     constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
     static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
     f32x16 acc[MT][NT];
@@ -639,7 +705,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r]) * a.unscale;   // power of two
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r]) * unscale;   // power of two
     const int HWo = a.Hout * a.Wout;
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
@@ -748,10 +814,19 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             if (tid < TM) b2s[tid] = a.bias2 ? a.bias2[tid] : 0.0f;
         }
         __syncthreads();
-        const float unscale2 = 1.0f / (CONVF_XSCALE * a.w2scale);
         const char* w2a = reinterpret_cast<const char*>(W2s) + (l31 * W2W + 8 * kh) * 2;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            // activation scale of the second conv: this wave's own tile maximum (the tile is a function of the sample
+            // and the layer geometry only, never of the batch)
+            unsigned tm = 0u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tm = max(tm, abs_bits(acc[mt][nt][r]));
+            float inv2;
+            const float s2 = f16x2_scale(wave_umax(tm), inv2);
+            const float unscale2 = inv2 / a.w2scale;                  // powers of two
             f32x16 a2h[MT], a2l[MT];
 #pragma unroll
             for (int m2 = 0; m2 < MT; ++m2)
@@ -764,7 +839,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     unsigned hq[4], lq[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        split2_pair_f16(acc[mt][nt][8 * tp + 2 * e] * CONVF_XSCALE, acc[mt][nt][8 * tp + 2 * e + 1] * CONVF_XSCALE, hq[e], lq[e]);
+                        split2_pair_f16(acc[mt][nt][8 * tp + 2 * e] * s2, acc[mt][nt][8 * tp + 2 * e + 1] * s2, hq[e], lq[e]);
                     const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(hq[0], hq[1], hq[2], hq[3]));
                     const f16x8 bl = __builtin_bit_cast(f16x8, make_uint4(lq[0], lq[1], lq[2], lq[3]));
 #pragma unroll
@@ -791,6 +866,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     const bool stats = NT == 1 && MT == 2 && a.stat_part != nullptr;     // block-uniform
     float* sb = reinterpret_cast<float*>(lds);
     if (stats) __syncthreads();                                  // main-loop / fused-conv LDS reads are done
+    unsigned am = 0u;                                            // amax side channel: bit pattern of max |stored value|
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if (pix[nt] < 0) continue;
@@ -806,11 +882,13 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     float v = acc[mt][nt][r];
                     if (rb) v += rv[mt][nt][r];
                     yp[ro] = v;
+                    am = max(am, abs_bits(v));
                     if (stats) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;
                 }
             }
         }
     }
+    if (a.amax_out) amax_publish(a.amax_out + b, am);
     if (stats) {
         __syncthreads();
         const int c = tid >> 2, q = tid & 3;
@@ -851,7 +929,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // SPL = 3: three bf16 terms, six products.  SPL = 2: two fp16 terms of the operand scaled by a power of two
-    // (activations x CONVF_XSCALE in the staging, weights per layer on the host), three products hh' + (hl' + lh'); the
+    // (activations x the sample's dynamic scale in the staging, weights per layer on the host), three products hh' + (hl' + lh'); the
     // dropped ll' term is <= 2^-24 |xy|.  Half the MFMAs and 2/3 of the LDS bytes at the accuracy of an fp32 chain.
     // MT = 1: 32-cout tiles (half a weight slab per block).  Same accumulation order, so the planner may pick it
     // freely; it is used when 64-cout tiles would leave CUs with fewer than two blocks.
@@ -868,7 +946,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     char* lds = smem;                                                  // 2 x [Xb | Wb]
     char* zunit = lds + 2 * buf_bytes;                                 // one all-zero 16-byte unit
     float* ssl = reinterpret_cast<float*>(zunit + 16);                 // [Cin_pad][2]
-    float* addv = ssl + a.Cin_pad * 2;                                 // [TM] bias + per-sample add of this cout tile
+    float* addv = ssl + a.Cin_pad * 2;                                 // [64] bias + per-sample add of this cout tile
+    unsigned* wmax = reinterpret_cast<unsigned*>(addv + 64);           // [4] per-wave share of the activation bound
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -899,8 +978,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             sy[u] = a.rowmap[ty * BH * a.stride + py];
             sx[u] = a.colmap[tx * BW * a.stride + px];
         }
-        for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
-            ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+        stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
         if (tid < TM) {
             const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
             addv[tid] = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
@@ -913,11 +991,18 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             const int p = tid + u * NTHR;
             const bool ok = p < PLANE && sy[u] >= 0 && sx[u] >= 0;
             udm[u] = ok ? sy[u] * a.Win + sx[u] : 0;
-            uok[u] = ok ? (SPL == 2 ? CONVF_XSCALE : 1.0f) : 0.0f;     // fp16 split: activations are staged scaled
+            uok[u] = ok ? 1.0f : 0.0f;
             uslot[u] = (p < PLANE ? p : PLANE) * 16;
         }
     }
     __syncthreads();
+    // fp16 split: activations are staged multiplied by the sample's power-of-two scale (bf16x3 needs none)
+    float xinv = 1.0f;
+    if (SPL == 2) {
+        const float xs = f16x2_scale(block_bound(wmax), xinv);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) uok[u] *= xs;
+    }
     // weight slab of this cout tile: host slabs hold 64 couts per (split, tap) row; a 32-cout block copies its half
     // of every row.  16 bytes per thread-slot.
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * SLAB64 +
@@ -1119,7 +1204,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
         pix[nt] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : -1;
     }
-    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, (a.bias || a.badd) ? addv : nullptr);
+    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, a.unscale * xinv,
+                                  (a.bias || a.badd) ? addv : nullptr);
 }
 
 // ===========================================================================
@@ -1133,7 +1219,6 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 // ===========================================================================
 // split scheme of the 1x1 kernels: 2 = two fp16 terms of the scaled operand (f16x2, see the 3x3 kernel), 3 = three bf16 terms
 #define CONVB1_SPL 2
-#define CONVB1_XSCALE (CONVB1_SPL == 2 ? CONVF_XSCALE : 1.0f)
 #define CONVB1_SLAB_BYTES (CONVB1_SPL * 4 * 64 * 16)   // splits x 4 octets x 64 couts x 8 ch
 template <bool VEC2, bool FUSE2>
 __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
@@ -1144,6 +1229,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
     char* lds = smem;                                                  // 2 x [Xb | Wb]
     float* ssl = reinterpret_cast<float*>(lds + 2 * BUF);              // [Cin_pad][2]
     float* addv = ssl + a.Cin_pad * 2;                                 // [TM] bias + per-sample add of this cout tile
+    unsigned* wmax = reinterpret_cast<unsigned*>(addv + TM);           // [4] per-wave share of the activation bound
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -1157,8 +1243,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
     const bool has_ss = a.ss != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
 
-    for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
-        ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+    stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
     if (tid < TM) {
         const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
         addv[tid] = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
@@ -1176,8 +1261,9 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         uoct[u] = VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u;
         const bool pvalid = p0 + upx[u] < HW;
         udm[u] = pvalid ? p0 + upx[u] : 0;
-        uok[u] = pvalid ? CONVB1_XSCALE : 0.0f;
+        uok[u] = pvalid ? 1.0f : 0.0f;                     // times the activation scale once the bound is known
     }
+    float xinv = 1.0f;
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)ct * (a.Cin_pad / KC) * CONVB1_SLAB_BYTES;
     const int aoff = (kh * TM + l31) * 16;                 // + (s*4 + 2j) * TM*16 + mt*32*16
     const int boff = (kh * TN + wn * 32 + l31) * 16;       // + (s*4 + 2j) * TN*16
@@ -1257,7 +1343,12 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         for (int cp = 0; cp < 4; ++cp) load_pairs(cp, 0);
 #pragma unroll
         for (int i = 0; i < NWU; ++i) load_w(i, 0);
-        __syncthreads();                                   // ssl / addv visible
+        __syncthreads();                                   // ssl / addv / wmax visible
+        if (SPL == 2) {
+            const float xs = f16x2_scale(block_bound(wmax), xinv);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) uok[u] *= xs;
+        }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -1345,7 +1436,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         const int p = p0 + wn * 32 + l31;
         pix[0] = p < a.Hout * a.Wout ? p : -1;
     }
-    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, (a.bias || a.badd) ? addv : nullptr);
+    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, a.unscale * xinv, (a.bias || a.badd) ? addv : nullptr);
 }
 
 // Input-stationary form of the 1x1 kernel for narrow inputs (Cin_pad <= 64) feeding many output channels:
@@ -1360,6 +1451,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
     char* xres = smem;                                                 // [stage 0..1][Xb]
     char* wbuf = smem + 2 * XB;                                        // [2][slab]
     float* ssl = reinterpret_cast<float*>(wbuf + 2 * CONVB1_SLAB_BYTES);
+    unsigned* wmax = reinterpret_cast<unsigned*>(ssl + a.Cin_pad * 2);   // [4] per-wave share of the activation bound
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -1374,8 +1466,8 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
     const float* xb = a.x + (long)b * a.x_bs;
     const bool has_ss = a.ss != nullptr;
 
-    for (int i = tid; i < a.Cin_pad * 2; i += NTHR)
-        ssl[i] = (has_ss && i < a.Cin * 2) ? a.ss[(long)b * a.Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+    stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
+    float xinv = 1.0f;
 
     // ---- stage the whole pixel tile (all channels) ----------------------------------
     {
@@ -1387,7 +1479,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
             uoct[u] = VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u;
             const bool pvalid = p0 + upx[u] < HW;
             udm[u] = pvalid ? p0 + upx[u] : 0;
-            uok[u] = pvalid ? CONVB1_XSCALE : 0.0f;
+            uok[u] = pvalid ? 1.0f : 0.0f;
         }
         for (int st = 0; st < nstage; ++st) {
             float pv[NU][8];
@@ -1405,7 +1497,14 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
                     }
                 }
             }
-            if (st == 0) __syncthreads();                   // ssl visible (behind the first stage's global loads)
+            if (st == 0) {
+                __syncthreads();                            // ssl / wmax visible (behind the first stage's global loads)
+                if (SPL == 2) {
+                    const float xs = f16x2_scale(block_bound(wmax), xinv);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) uok[u] *= xs;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 unsigned hq[4], mq[4], lq[4];
@@ -1522,14 +1621,14 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
         }
         __syncthreads();
         if (++st == nstage) {
-            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem);
+            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, a.unscale * xinv);
             st = 0;
             ++ctl;
         }
     }
 }
 
-size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 64 * 4 + 16; }
+size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 64 * 4 + 16 + 16; }
 
 bool convb1_fits(const ConvArgs& a) {
     return a.ks == 1 && a.stride == 1 && (a.Cin_pad % 32) == 0 && a.wb != nullptr && convb1_lds_bytes(a) <= 150 * 1024;
@@ -1537,8 +1636,12 @@ bool convb1_fits(const ConvArgs& a) {
 
 size_t convb1_weight_bytes(int Cout, int Cin_pad) { return (size_t)((Cout + 63) / 64) * (Cin_pad / 32) * CONVB1_SLAB_BYTES; }
 
+// a split-operand launch without a bound on its input would have to guess the activation scale: refuse it
+static bool has_act_bound(const ConvArgs& a) { return a.amax_in != nullptr || a.amax_in_const > 0.0f; }
+
 hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s) {
     if (!convb1_fits(a)) return hipErrorInvalidValue;
+    if (CONVB1_SPL == 2 && !has_act_bound(a)) return hipErrorInvalidValue;
     dim3 grid(a.tiles_x * a.cout_tiles, a.B);
     const size_t lds = convb1_lds_bytes(a);
     const bool vec2 = ((a.Hin * a.Win) % 2 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && (a.x_bs % 2 == 0);
@@ -1562,7 +1665,7 @@ hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s) {
 
 size_t convb_lds_bytes(const ConvArgs& a, int tm, int spl) {
     const size_t pp1 = (size_t)a.PH * a.PW + 1;
-    return 2 * (spl * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + 64) * 4 + 16;
+    return 2 * (spl * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + 64) * 4 + 16 + 16;
 }
 
 bool convb_fits(const ConvArgs& a) {
@@ -1663,7 +1766,18 @@ void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, in
     }
 }
 
-float convb1_xscale() { return CONVB1_XSCALE; }
+bool convb1_is_f16() { return CONVB1_SPL == 2; }
+
+float convf_scale_for_bound(float bound) {
+    uint32_t u;
+    __builtin_memcpy(&u, &bound, 4);
+    int f = 127 + CONVF_TARGET_EXP + 127 - (int)((u >> 23) & 0xffu);
+    f = f < 27 ? 27 : (f > 187 ? 187 : f);
+    const uint32_t sb = (uint32_t)f << 23;
+    float sc;
+    __builtin_memcpy(&sc, &sb, 4);
+    return sc;
+}
 
 void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale) {
     if (CONVB1_SPL == 2) {
@@ -1708,6 +1822,7 @@ void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, i
 
 hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     if (!convb_fits(a)) return hipErrorInvalidValue;
+    if ((variant == CV_F64 || variant == CV_F32) && !has_act_bound(a)) return hipErrorInvalidValue;
     dim3 grid(a.tiles_x * a.tiles_y * a.cout_tiles, a.B);
     const bool two = (long)a.PH * a.PW > 256;            // patch units per thread
     if (variant == CV_F64) {                              // two-term fp16 split
@@ -1809,6 +1924,15 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
     for (int co = 0; co < 4; ++co) {
         if (co < CO)
             *reinterpret_cast<float4*>(yb + (long)co * HW) = make_float4(acc[co][0] + bv[co], acc[co][1] + bv[co], acc[co][2] + bv[co], acc[co][3] + bv[co]);
+    }
+    if (a.amax_out) {                                          // lanes that returned early simply do not take part
+        unsigned am = 0u;
+#pragma unroll
+        for (int co = 0; co < 4; ++co)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (co < CO) am = max(am, abs_bits(acc[co][e] + bv[co]));
+        atomicMax(a.amax_out + b, am);
     }
 }
 
@@ -2344,6 +2468,7 @@ __global__ __launch_bounds__(256) void fa_reducer_kernel(FaReducerArgs a) {
         if (row < a.rows) {
             const long bi = row / a.n, i = row - bi * a.n;
             a.u[(bi * Out + o) * a.n + i] = acc;
+            if (a.amax_out) atomicMax(a.amax_out + bi, abs_bits(acc));
         }
     }
 }
@@ -2445,6 +2570,7 @@ __device__ __forceinline__ void fa_reducer_mfma_body(const FaReducerArgs& a, int
     }
     const long row = row0 + l31;
     const long bi = row / a.n, ii = row - bi * a.n;
+    unsigned am_u = 0u;                                    // amax side channel: max |u| over this lane's row
     for (int o0 = 0; o0 < Out; o0 += 128) {                // Linear(Hid, Out) + bias, 128 outputs at a time
         __syncthreads();
         const int oc = min(128, Out - o0);
@@ -2466,10 +2592,24 @@ __device__ __forceinline__ void fa_reducer_mfma_body(const FaReducerArgs& a, int
                 const int o = o0 + mt * 32 + drow(r, kh);
                 if (o < Out) {
                     const float v = acc[r] + b2v[r];
-                    if (a.u && row < a.rows) a.u[(bi * Out + o) * a.n + ii] = v;
+                    if (a.u && row < a.rows) {
+                        a.u[(bi * Out + o) * a.n + ii] = v;
+                        am_u = max(am_u, abs_bits(v));
+                    }
                     if (a.qk) X3[o * FARM_RP + l31] = v;
                 }
             }
+        }
+    }
+    if (a.amax_out) {
+        // a block's 32 rows usually belong to one sample: one atomic per wave; otherwise one per lane
+        const long bi0 = __builtin_amdgcn_readfirstlane((int)bi);
+        const bool live = row < a.rows;
+        if (__all((!live || bi == bi0) ? 1 : 0)) {
+            const unsigned m = wave_umax(live ? am_u : 0u);
+            if (lane == 0 && m) atomicMax(a.amax_out + bi0, m);
+        } else if (live) {
+            atomicMax(a.amax_out + bi, am_u);
         }
     }
     if (a.qk) {                                            // fused to_qk: qk[m][r] = sum_o wqk[o][m] * X3[o][r] (+ bias)
@@ -3195,7 +3335,13 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs a) {
     const float sh = a.ss ? a.ss[((long)b * a.C + c) * 2 + 1] : 0.0f;
     const float* xs = a.x + (long)b * a.x_bs + (long)c * a.HW;
     float* ys = a.y + ((long)b * a.C + c) * a.HW;
-    for (int i = threadIdx.x; i < a.HW; i += 256) ys[i] = act_apply(xs[i] * sc + sh, a.act);
+    unsigned am = 0u;
+    for (int i = threadIdx.x; i < a.HW; i += 256) {
+        const float v = act_apply(xs[i] * sc + sh, a.act);
+        ys[i] = v;
+        am = max(am, abs_bits(v));
+    }
+    if (a.amax_out) amax_publish(a.amax_out + b, am);
 }
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(apply_kernel, dim3(a.C, a.B), dim3(256), 0, s, a);
@@ -3333,8 +3479,13 @@ __global__ __launch_bounds__(256) void fourier_combine_kernel(FourierCombineArgs
     const float e = a.e ? a.e[(long)b * a.C + c] : 0.0f;
     const float* sk = a.skip + (long)b * a.skip_bs + (long)c * a.HW;
     float* ys = a.y + (long)b * a.y_bs + (long)c * a.HW;
-    for (int i = threadIdx.x; i < a.HW; i += 256)
-        ys[i] = sk[i] + act_apply(a.a[base + i] + a.b[base + i] + e, ACT_GELU);
+    unsigned am = 0u;
+    for (int i = threadIdx.x; i < a.HW; i += 256) {
+        const float v = sk[i] + act_apply(a.a[base + i] + a.b[base + i] + e, ACT_GELU);
+        ys[i] = v;
+        am = max(am, abs_bits(v));
+    }
+    if (a.amax_out) amax_publish(a.amax_out + b, am);
 }
 hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(fourier_combine_kernel, dim3(a.C, a.B), dim3(256), 0, s, a);
@@ -3445,6 +3596,21 @@ hipError_t launch_metric_rel_l2_ch(const float* yhat, const float* y, int B, int
                                    float* scratch, hipStream_t s) {
     hipLaunchKernelGGL(metric_plane_ch_kernel, dim3((unsigned)((long)B * T * C)), dim3(256), 0, s, yhat, y, C, H, W, spec, scratch);
     hipLaunchKernelGGL(metric_finish_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, scratch, B, T, C, eps, frame_out, seq_out);
+    return hipGetLastError();
+}
+
+// per-sample max |x| of a [B, n] tensor: grid (chunks, B); one atomic per wave
+__global__ __launch_bounds__(256) void amax_kernel(const float* x, long x_bs, long n, unsigned* amax) {
+    const int b = blockIdx.y;
+    const float* xs = x + (long)b * x_bs;
+    unsigned am = 0u;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) am = max(am, abs_bits(xs[i]));
+    amax_publish(amax + b, am);
+}
+hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax, hipStream_t s) {
+    long chunks = (n + 256 * 16 - 1) / (256 * 16);
+    chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)chunks, B), dim3(256), 0, s, x, x_bs, n, amax);
     return hipGetLastError();
 }
 

@@ -282,6 +282,16 @@ class Engine:
                                                ws.data_ptr(), ws.numel(), self._stream(z)), "lns_rollout_latent")
         return out, z_last
 
+    def check_finite(self, B, device):
+        """Raises LnsError naming the first layer / sample whose output of the LAST run for batch B held inf or NaN
+        (synchronises the device's current stream; reads a few KB of the workspace back)."""
+        import torch
+        ws = self._ws.get((B, torch.device(device)))
+        if ws is None:
+            raise LnsError("no run for batch %d on %s yet" % (B, device))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(ws.device).cuda_stream)
+        self._check(self._L.lns_check_finite(self._h, int(B), ws.data_ptr(), ws.numel(), stream), "lns_check_finite")
+
     # -- diagnostics ----------------------------------------------------------------
     def trace_enable(self, on=True):
         self._check(self._L.lns_trace_enable(self._h, int(on)), "lns_trace_enable")

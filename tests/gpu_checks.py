@@ -30,20 +30,32 @@ def rng(seed):
 
 
 def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), up=None, ss=False, act_in=0,
-              act_out=0, res=False, badd=False, bias=True, variant=-1, seed=0):
-    """Returns (rel_l2 error, output shape) of lns_op_conv2d vs the oracle composition."""
+              act_out=0, res=False, badd=False, bias=True, variant=-1, seed=0, xscale=1.0, sample_scales=None,
+              heavy_w=False, xdist="normal", fp64=False):
+    """Returns (rel_l2 error, output shape) of lns_op_conv2d vs the oracle composition.
+    xscale / sample_scales: magnitude of the activations (per sample); heavy_w: heavy-tailed (Student-t, 2 dof)
+    weights; xdist "lognormal": activations spread over several decades; fp64: additionally returns the error
+    against an fp64 evaluation of the same composition (third element)."""
     L = _lib.lib()
     r = rng(seed)
     x = r.standard_normal((B, Cin, H, W)).astype(np.float32)
-    w = (r.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
-    bv = r.standard_normal(Cout).astype(np.float32) * 0.1 if bias else None
+    if xdist == "lognormal":
+        x = (x * np.exp(3.0 * r.standard_normal((B, Cin, H, W)))).astype(np.float32)
+    x = (x * np.float32(xscale)).astype(np.float32)
+    if sample_scales is not None:
+        x = (x * np.asarray(sample_scales, np.float32).reshape(B, 1, 1, 1)).astype(np.float32)
+    if heavy_w:
+        w = (r.standard_t(2.0, size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    else:
+        w = (r.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bv = (r.standard_normal(Cout) * 0.1 * xscale).astype(np.float32) if bias else None
     if pad is None:
         p = dil * (k - 1) // 2
         pad = (p, p, p, p)
     ssv = None
     xin = x
     if ss:
-        ssv = np.stack([1.0 + 0.2 * r.standard_normal((B, Cin)), 0.1 * r.standard_normal((B, Cin))], -1).astype(np.float32)
+        ssv = np.stack([1.0 + 0.2 * r.standard_normal((B, Cin)), 0.1 * xscale * r.standard_normal((B, Cin))], -1).astype(np.float32)
         xin = x * ssv[:, :, 0][:, :, None, None] + ssv[:, :, 1][:, :, None, None]
     if act_in == 1:
         xin = lns_oracle.swish(xin)
@@ -73,16 +85,59 @@ def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), u
     ssd = _dev(ssv) if ssv is not None else None
     resd = _dev(res_v) if res_v is not None else None
     baddd = _dev(badd_v) if badd_v is not None else None
+    amax = torch.zeros(B, dtype=torch.int32, device="cuda")
     rc = L.lns_op_conv2d(xd.data_ptr(), B, Cin, H, W, Hv, Wv, _hp(w), _hp(bv), Cout, k, stride, dil,
                          pad[0], pad[1], pad[2], pad[3], mode[0], mode[1],
                          ssd.data_ptr() if ssd is not None else None, act_in, act_out,
                          resd.data_ptr() if resd is not None else None,
-                         baddd.data_ptr() if baddd is not None else None, y.data_ptr(), variant, _stream())
+                         baddd.data_ptr() if baddd is not None else None, y.data_ptr(), variant, _stream(),
+                         amax.data_ptr())
     assert rc == 0, "lns_op_conv2d rc=%d" % rc
     torch.cuda.synchronize()
     out = y.cpu().numpy()
     assert np.isfinite(out).all(), "non-finite / unwritten outputs"
-    return rel_l2(out, ref), ref.shape
+    # amax side channel: bit pattern of max |y| per sample, exactly
+    got = amax.cpu().numpy().view(np.float32)
+    want = np.abs(out).reshape(B, -1).max(1)
+    assert np.array_equal(got, want), ("amax side channel", got, want)
+    # every sample on its own (samples of one batch may differ by orders of magnitude)
+    err = max(rel_l2(out[i], ref[i]) for i in range(B))
+    if fp64:
+        r64 = conv_case_fp64(x, w, bv, stride, dil, pad, mode, up, ssv, act_in, badd_v, act_out, res_v)
+        return err, ref.shape, max(rel_l2(out[i], r64[i]) for i in range(B))
+    return err, ref.shape
+
+
+def conv_case_fp64(x, w, bv, stride, dil, pad, mode, up, ssv, act_in, badd_v, act_out, res_v):
+    """The same composition evaluated in fp64 (torch CPU): the tie-breaker for the split-operand kernels."""
+    import torch.nn.functional as F
+    xt = torch.from_numpy(x).double()
+    if ssv is not None:
+        st = torch.from_numpy(ssv).double()
+        xt = xt * st[:, :, 0][:, :, None, None] + st[:, :, 1][:, :, None, None]
+    if act_in == 1:
+        xt = xt * torch.sigmoid(xt)
+    elif act_in == 2:
+        xt = F.gelu(xt)
+    if up is not None:
+        Hv, Wv = up
+        H, W = xt.shape[-2:]
+        iy = torch.clamp(torch.floor(torch.arange(Hv).float() * (0.5 if Hv == 2 * H else np.float32(H) / np.float32(Hv))).long(), max=H - 1)
+        ix = torch.clamp(torch.floor(torch.arange(Wv).float() * (0.5 if Wv == 2 * W else np.float32(W) / np.float32(Wv))).long(), max=W - 1)
+        xt = xt[:, :, iy][:, :, :, ix]
+    xt = F.pad(xt, (pad[2], pad[3], 0, 0), mode="circular" if mode[1] else "constant")
+    xt = F.pad(xt, (0, 0, pad[0], pad[1]), mode="circular" if mode[0] else "constant")
+    y = F.conv2d(xt, torch.from_numpy(w).double(), torch.from_numpy(bv).double() if bv is not None else None,
+                 stride=stride, dilation=dil)
+    if badd_v is not None:
+        y = y + torch.from_numpy(badd_v).double()[:, :, None, None]
+    if act_out == 1:
+        y = y * torch.sigmoid(y)
+    elif act_out == 2:
+        y = F.gelu(y)
+    if res_v is not None:
+        y = y + torch.from_numpy(res_v).double()
+    return y.numpy()
 
 
 CONV_CASES = [
@@ -147,6 +202,50 @@ for _v in range(6):   # every tile variant on the same problem
                            mode=(1, 1), variant=_v))
     CONV_CASES.append(dict(B=2, Cin=64, Cout=(32 if _v == 5 else 128 if _v in (0, 2) else 64), H=20, W=36, k=1,
                            variant=_v, ss=True, act_in=1))
+
+
+# Domain of the split-operand (f16x2) kernels -- variants 11 / 13 (3x3) and 7 / 8 (1x1): activation magnitudes from
+# 1e-5 to 3e3 and beyond (the fixed x16 scale of round 1 overflowed at 4094 and lost the low term below 8e-3),
+# different magnitudes per sample of one batch, activations spread over several decades, heavy-tailed weights,
+# un-normalised inputs (no GroupNorm prologue) and inputs behind a scale/shift + Swish prologue.
+DOMAIN_CASES = []
+for _xs in (1e-12, 1e-5, 1e-3, 3e-2, 1.0, 60.0, 3e3, 1e6, 1e12):
+    DOMAIN_CASES.append(dict(B=2, Cin=64, Cout=64, H=16, W=16, k=3, variant=11, xscale=_xs))
+    DOMAIN_CASES.append(dict(B=2, Cin=64, Cout=64, H=16, W=16, k=3, variant=11, xscale=_xs, ss=True, act_in=1, res=False))
+    DOMAIN_CASES.append(dict(B=2, Cin=64, Cout=128, H=16, W=16, k=1, variant=7, xscale=_xs))
+    DOMAIN_CASES.append(dict(B=2, Cin=64, Cout=192, H=8, W=16, k=1, variant=8, xscale=_xs, ss=True))
+DOMAIN_CASES += [
+    dict(B=4, Cin=64, Cout=64, H=16, W=16, k=3, variant=11, sample_scales=[1e-4, 1.0, 2e3, 3e-2]),
+    dict(B=4, Cin=64, Cout=64, H=16, W=16, k=3, variant=13, sample_scales=[1e-4, 1.0, 2e3, 3e-2], ss=True, act_in=1),
+    dict(B=4, Cin=32, Cout=64, H=16, W=16, k=1, variant=7, sample_scales=[5e3, 1e-5, 1.0, 40.0]),
+    dict(B=2, Cin=64, Cout=64, H=16, W=16, k=3, variant=11, heavy_w=True),
+    dict(B=2, Cin=128, Cout=128, H=16, W=16, k=3, variant=11, heavy_w=True, xscale=500.0, act_out=2),
+    dict(B=2, Cin=64, Cout=128, H=16, W=16, k=1, variant=7, heavy_w=True, xscale=1e-3),
+    dict(B=2, Cin=64, Cout=64, H=16, W=16, k=3, variant=11, xdist="lognormal"),
+    dict(B=2, Cin=64, Cout=64, H=16, W=16, k=1, variant=7, xdist="lognormal", heavy_w=True),
+]
+
+
+def conv_nonfinite_case():
+    """One inf in sample 1: sample 0 stays finite and exact, sample 1's outputs and amax are non-finite."""
+    L = _lib.lib()
+    r = rng(5)
+    B, C, H, W = 2, 64, 16, 16
+    x = r.standard_normal((B, C, H, W)).astype(np.float32)
+    x[1, 3, 5, 7] = np.inf
+    w = (r.standard_normal((C, C, 3, 3)) / 24.0).astype(np.float32)
+    xd = _dev(x)
+    y = torch.zeros((B, C, H, W), dtype=torch.float32, device="cuda")
+    amax = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rc = L.lns_op_conv2d(xd.data_ptr(), B, C, H, W, H, W, _hp(w), None, C, 3, 1, 1, 1, 1, 1, 1, 1, 1, None, 0, 0, None, None,
+                         y.data_ptr(), 11, _stream(), amax.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    out = y.cpu().numpy()
+    am = amax.cpu().numpy().view(np.float32)
+    ref0 = lns_oracle.conv2d(x[:1], w, None, 1, 1, (1, 1, 1, 1), (1, 1))
+    return bool(np.isfinite(out[0]).all() and rel_l2(out[0], ref0[0]) < 2e-6 and not np.isfinite(out[1]).all()
+                and not np.isfinite(am[1]) and np.isfinite(am[0]))
 
 
 def gn_case(B, C, HW, groups, eps, premul=False, seed=0):

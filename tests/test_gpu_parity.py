@@ -46,6 +46,35 @@ def test_conv_kernel(idx, case):
     assert err < KERNEL_TOL, (case, err)
 
 
+def _domain_cases():
+    import gpu_checks as gc
+    return list(enumerate(gc.DOMAIN_CASES))
+
+
+@pytest.mark.parametrize("idx,case", _domain_cases())
+def test_split_operand_domain(idx, case):
+    """f16x2 kernels over the whole fp32-like input domain (activation magnitudes 1e-12 .. 1e12, per-sample
+    magnitudes 5e3 vs 1e-5 in one batch, heavy-tailed weights, decades-wide activations; with and without a
+    GroupNorm-style prologue): every SAMPLE within the kernel tolerance (2e-6 rel-L2) of the fp32 oracle AND of an
+    fp64 evaluation of the same composition."""
+    _need_gpu()
+    import gpu_checks as gc
+    err, _, e64 = gc.conv_case(seed=100 + idx, bias=False, fp64=True, **case)
+    assert err < KERNEL_TOL, (case, err, e64)
+    assert e64 < KERNEL_TOL, (case, err, e64)
+
+
+def test_split_operand_extremes():
+    """Beyond the clamp of the dynamic scale (|x| ~ 1e-25: the low fp16 term is subnormal) the kernels degrade
+    gracefully -- finite, ~1e-5 accurate -- and a non-finite input gives non-finite outputs and a non-finite amax
+    (loud, as in fp32), never a silently wrong field."""
+    _need_gpu()
+    import gpu_checks as gc
+    err, _ = gc.conv_case(B=2, Cin=64, Cout=64, H=16, W=16, k=3, variant=11, xscale=1e-25, bias=False, seed=7)
+    assert err < 1e-3
+    assert gc.conv_nonfinite_case()
+
+
 @pytest.mark.parametrize("case", [
     dict(B=2, C=64, HW=1024, groups=32, eps=1e-6), dict(B=2, C=128, HW=256, groups=1, eps=1e-5),
     dict(B=3, C=64, HW=4097, groups=8, eps=1e-5), dict(B=2, C=128, HW=105, groups=1, eps=1e-5, premul=True),
@@ -127,6 +156,52 @@ def test_rollout_matches_reference_golden(case):
     assert np.array_equal(lat2, lat)
 
 
+# Long horizons of BASELINE configs 3 / 4 / 5 (T = 64 / 128 / 256).  The random-init dynamics amplify rounding noise
+# exponentially: the reference's OWN fp32 run is off its fp64 run by `ref_self_err[t]` (stored in the fixture;
+# 2.6e-4 @256 for NS2d, 1.8e-3 @64 for SW-5ch, O(1) beyond t ~ 90 for the conditional two-phase model), so at these
+# horizons 1e-4 against the fp32 run is not a property any two fp32 implementations share.  Stated tolerance per
+# horizon: against the reference's fp64 run the engine must be no further than 1.5x the reference's own fp32 noise
+# (floor 2e-5) while that noise is below 1e-2 (linearised regime); the 1e-4 gate against the fp32 run applies
+# wherever the reference's noise is below 3e-5; later steps are reported, not gated (chaotic regime).
+LONG_CASES = ["sw_96x192x5_T64", "twophase_cond_T128", "ns2d_128_T256"]
+LINEAR_REGIME = 1e-2
+
+
+@pytest.mark.parametrize("case", LONG_CASES)
+def test_long_horizon_rollout_vs_reference(case):
+    _need_gpu()
+    import gpu_checks as gc
+    meta, g = load_golden(case)
+    args = case_args(meta)
+    model, _ = gc.build_models(args, meta["weight_seed"])
+    x, param = case_inputs(meta, args)
+    xd = torch.from_numpy(x).cuda()
+    T = meta["T"]
+    extra = (torch.from_numpy(param).cuda(),) if param is not None else ()
+    dec = model.predict(xd, T, *extra, to_x=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dec).all()
+    dec = dec.cpu().numpy()
+    sub = meta["sub"]
+    noise = g["ref_self_err"]
+    report, gated = [], 0
+    for i, s in enumerate(meta["steps"]):
+        f = dec[:, s - 1][..., ::sub, ::sub]
+        e_dec, e64, n = rel_l2(f, g["dec"][:, i]), rel_l2(f, g["dec_f64"][:, i]), float(noise[s - 1])
+        report.append((s, e_dec, e64, n))
+        if n <= LINEAR_REGIME:
+            gated += 1
+            assert e64 <= max(1.5 * n, 2e-5), report
+        if n <= 3e-5:
+            assert e_dec < ROLLOUT_TOL, report
+    print(case, report)
+    assert gated >= 2, report
+    # per-frame norms over the whole horizon, where the reference itself is reproducible
+    nrm = np.sqrt((dec.astype(np.float64) ** 2).sum((-1, -2)))
+    ok = noise <= 1e-4
+    np.testing.assert_allclose(nrm[:, ok], g["dec_norm_f64"][:, ok], rtol=1e-3)
+
+
 def test_batch_shard_equivalence_and_b1():
     """Trajectories are independent: a sample's result must not depend on the batch it
     rides in (this is what makes trajectory sharding over GPUs collective-free), and B=1
@@ -175,6 +250,30 @@ def test_module_api_surface():
     with torch.no_grad():
         getattr(model.propagator.out_proj, "1").bias.add_(1.0)
     assert not torch.equal(model.propagator(z), z1)
+
+
+def test_check_finite_names_the_layer():
+    """lns_check_finite: clean after a normal rollout; after a rollout whose input holds an inf it names the first
+    layer whose output went non-finite (and the sample) instead of leaving silently broken fields."""
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    from lns_amd._lib import LnsError
+    args = config.preset("ns2d_mini")
+    model, _ = gc.build_models(args, 1)
+    x = filler.normal("x", (3, args.in_channels, args.Ly, args.Lx), 7)
+    xd = torch.from_numpy(x).cuda()
+    eng = model._engine(xd)
+    y = model.predict(xd, 3, to_x=True)
+    eng.check_finite(3, xd.device)
+    assert torch.isfinite(y).all()
+    x[2, 1, 5, 9] = np.inf
+    xb = torch.from_numpy(x).cuda()
+    y = model.predict(xb, 3, to_x=True)
+    with pytest.raises(LnsError, match=r"non-finite values in the output of .*encoder.*sample 2"):
+        eng.check_finite(3, xb.device)
+    assert torch.isfinite(y[:2]).all() and not torch.isfinite(y[2]).all()
+    assert torch.equal(y[:2], model.predict(xd, 3, to_x=True)[:2])       # the clean samples are untouched, bit for bit
 
 
 def test_overlapped_rollout_equals_single_stream():

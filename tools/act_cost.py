@@ -18,7 +18,7 @@ ss = torch.stack([1 + 0.1 * torch.randn(B, Cin), 0.1 * torch.randn(B, Cin)], -1)
 y = torch.empty(B, Cout, H, W, device="cuda")
 for it in range(20):
     rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, H, W, gc._hp(w), gc._hp(bias), Cout, k, 1, 1, 1, 1, 1, 1, 1, 1,
-                         ss.data_ptr(), 0, act_out, None, None, y.data_ptr(), 11, None)
+                         ss.data_ptr(), 0, act_out, None, None, y.data_ptr(), 11, None, None)
     assert rc == 0
 torch.cuda.synchronize()
 print("done", act_out)

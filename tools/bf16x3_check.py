@@ -29,7 +29,7 @@ def run(B, Cin, Cout, H, W, dil, mode, variant, scale=1.0, seed=0):
     xd = torch.from_numpy(x).cuda()
     y = torch.full(ref.shape, float("nan"), dtype=torch.float32, device="cuda")
     rc = L.lns_op_conv2d(xd.data_ptr(), B, Cin, H, W, H, W, G._hp(w), None, Cout, 3, 1, dil, dil, dil, dil, dil,
-                         mode[0], mode[1], None, 0, 0, None, None, y.data_ptr(), variant, G._stream())
+                         mode[0], mode[1], None, 0, 0, None, None, y.data_ptr(), variant, G._stream(), None)
     assert rc == 0, rc
     out = y.cpu().numpy().astype(np.float64)
     assert np.isfinite(out).all()

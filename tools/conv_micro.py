@@ -32,7 +32,7 @@ for name in which:
     y = torch.empty(B, Cout, Hv, Wv, device="cuda")
     for it in range(3):
         rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, Hv, Wv, gc._hp(w), gc._hp(bias), Cout, k, 1, 1, p, p, p, p, 1, 1,
-                             ss.data_ptr(), c["act"], 0, None, None, y.data_ptr(), VARIANT if k == 3 else -1, None)
+                             ss.data_ptr(), c["act"], 0, None, None, y.data_ptr(), VARIANT if k == 3 else -1, None, None)
         assert rc == 0
     torch.cuda.synchronize()
     print(name, "done")

@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblns_hip.so")
+# LNS_HIP_LIB: A/B runs of two builds of the library inside one GPU call (tools/ab_bench.sh); never set in production
+LIB_PATH = os.environ.get("LNS_HIP_LIB") or os.path.join(_HERE, "liblns_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 LNS_MAX_STAGES = 8
@@ -108,7 +109,8 @@ def lib():
     L.lns_propagate.argtypes = [vp, vp, vp, i, i, i, vp, vp, c.c_size_t, vp]
     L.lns_rollout.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, c.c_size_t, vp]
     L.lns_rollout_latent.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, c.c_size_t, vp]
-    L.lns_check_finite.argtypes = [vp, i, vp, c.c_size_t, vp]
+    if hasattr(L, "lns_check_finite"):      # (absent from older builds loaded through LNS_HIP_LIB for A/B runs)
+        L.lns_check_finite.argtypes = [vp, i, vp, c.c_size_t, vp]
     L.lns_trace_enable.argtypes = [vp, i]
     L.lns_trace_count.argtypes = [vp]
     L.lns_trace_info.argtypes = [vp, i, c.c_char_p, i, i64p]

@@ -262,7 +262,9 @@ struct TRef {
     // bound on |raw values| for the split-operand consumers: per-sample running maximum recorded by the producer
     // (tagged pointer to [B] unsigned) or an analytic constant (LayerNorm / InstanceNorm outputs); neither: unknown
     uint64_t amax = 0; float amax_const = 0.0f;
-    bool bounded() const { return amax != 0 || amax_const > 0.0f; }
+    // pending GroupNorm: |gamma| sqrt(n_group) + |beta| bounds the normalised tensor whatever the data (layer constant)
+    float gn_bound = 0.0f;
+    bool bounded() const { return amax != 0 || amax_const > 0.0f || (ss != 0 && gn_bound > 0.0f); }
     bool pending() const { return ss != 0 || act != ACT_NONE || vH != 0; }
 };
 
@@ -361,6 +363,8 @@ struct Planner {
         x.ss = tag(SP_WS, x.ss_off); x.ss_owned = true;
         op.gn.ss = as_ptr<float>(x.ss); op.gn.B = B;
         op.bytes = 2.0 * B * x.C * x.H * x.W * 4;
+        // |(v - mean) rstd| <= sqrt(n - 1) over a group of n values (biased variance), for any data
+        x.gn_bound = (vg >= 0 ? vec_absmax(vg) : 1.0f) * sqrtf((float)(x.C / groups) * x.H * x.W) + (vb >= 0 ? vec_absmax(vb) : 0.0f);
         // Fed by the 3x3 split-operand kernel right before it (nothing in between but traces), 128-pixel tiles
         // covering the plane exactly: the conv epilogue leaves per-tile (mean, M2) and this op only merges them.
         // Layer-static decision, so results do not depend on the batch.
@@ -449,8 +453,10 @@ struct Planner {
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
         a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / pk.wscale : 1.0f;   // x 1/S in the kernel
-        a.amax_in = as_ptr<const unsigned>(in.amax); a.amax_in_const = in.amax_const;
-        if (want_amax) { out.amax = new_amax(name); out.amax_const = 0.0f; a.amax_out = as_ptr<unsigned>(out.amax); }
+        if (in.ss != 0 && in.gn_bound > 0.0f) { a.amax_in_const = in.gn_bound; a.bound_final = 1; }   // GroupNorm output: layer constant
+        else { a.amax_in = as_ptr<const unsigned>(in.amax); a.amax_in_const = in.amax_const; }
+        out.amax = 0; out.amax_const = 0.0f; out.gn_bound = 0.0f;
+        if (want_amax && !out_forced && g.variant != CV_THIN) { out.amax = new_amax(name); a.amax_out = as_ptr<unsigned>(out.amax); }
         a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.sel_kc_log2;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
@@ -480,31 +486,34 @@ struct Planner {
         return emit_conv(in, pack, 1, 1, 1, pad, 0, 0, act_out, res, 0, out_forced, name, fuse_pack, want_amax);
     }
     TRef conv_same3(const TRef& in, int pack, int dil, int my, int mx, int act_out, const TRef* res, uint64_t badd,
-                    const std::string& name) {
+                    const std::string& name, bool want_amax = true) {
         const int pad[4] = {dil, dil, dil, dil};
-        return emit_conv(in, pack, 3, 1, dil, pad, my, mx, act_out, res, badd, nullptr, name);
+        return emit_conv(in, pack, 3, 1, dil, pad, my, mx, act_out, res, badd, nullptr, name, -1, want_amax);
     }
 
     // ---- composite modules ----------------------------------------------------
-    TRef lower_res(const Layer& l, TRef x) {
+    // `raw_out`: the block's output will be read un-normalised by a split-operand convolution (next layer is a conv /
+    // an up-sampling conv / a block with a channel_up) and needs the amax side channel; tensors that only feed
+    // GroupNorm-prologue convolutions (analytic bound) or residual adds do not.
+    TRef lower_res(const Layer& l, TRef x, bool raw_out) {
         if (x.pending()) throw std::runtime_error("ResidualBlock input must be materialised: " + l.name);
         TRef skip = x;
         bool skip_owned = false;
-        if (l.chup >= 0) { skip = conv_same1(x, l.chup, ACT_NONE, nullptr, nullptr, l.name + ".channel_up"); skip_owned = true; }
+        if (l.chup >= 0) { skip = conv_same1(x, l.chup, ACT_NONE, nullptr, nullptr, l.name + ".channel_up", -1, false); skip_owned = true; }
         TRef xin = x; xin.owned = false;
         emit_gn(xin, 32, 1e-6f, l.g1, l.b1, 0, l.name + ".gn1");
         xin.act = ACT_SWISH;
-        TRef h1 = conv_same3(xin, l.conv1, 1, l.mode_y, l.mode_x, ACT_NONE, nullptr, 0, l.name + ".conv1");
+        TRef h1 = conv_same3(xin, l.conv1, 1, l.mode_y, l.mode_x, ACT_NONE, nullptr, 0, l.name + ".conv1", false);
         free_t(xin);   // releases the stats buffer only (xin does not own x)
         emit_gn(h1, 32, 1e-6f, l.g2, l.b2, 0, l.name + ".gn2");
         h1.act = ACT_SWISH;
-        TRef out = conv_same3(h1, l.conv2, 1, l.mode_y, l.mode_x, ACT_NONE, &skip, 0, l.name + ".conv2");
+        TRef out = conv_same3(h1, l.conv2, 1, l.mode_y, l.mode_x, ACT_NONE, &skip, 0, l.name + ".conv2", raw_out);
         free_t(h1);
         if (skip_owned) free_t(skip);
         return out;
     }
 
-    TRef lower_sa(const Layer& l, TRef x) {
+    TRef lower_sa(const Layer& l, TRef x, bool raw_out) {
         if (x.pending()) throw std::runtime_error("SABlock input must be materialised");
         const int n = x.H * x.W, inner = l.heads * l.dim_head;
         if (l.pe >= 0 && n > l.pe_len) throw std::runtime_error("SABlock: more tokens than positional table rows");
@@ -536,7 +545,7 @@ struct Planner {
             plan->ops.push_back(op);
         }
         free_t(qkv);
-        TRef out = conv_same1(o, l.proj, ACT_NONE, &x, nullptr, l.name + ".proj_out");
+        TRef out = conv_same1(o, l.proj, ACT_NONE, &x, nullptr, l.name + ".proj_out", -1, raw_out);
         free_t(o);
         return out;
     }
@@ -560,7 +569,7 @@ struct Planner {
         return const_floats(cs);
     }
 
-    TRef lower_fa(const Layer& l, TRef x) {
+    TRef lower_fa(const Layer& l, TRef x, bool raw_out) {
         if (x.pending()) throw std::runtime_error("FABlock2D input must be materialised");
         const int C = x.C, H = x.H, W = x.W, heads = l.heads, dh = l.dim_head, lat = l.fa_lat, DK = l.fa_dk;
         TRef xin = x; xin.owned = false;
@@ -621,8 +630,8 @@ struct Planner {
                 }
             }
             arena.release(mx_off); arena.release(my_off);
-            qkx = conv_same1(ux, l.qkx, ACT_NONE, nullptr, nullptr, l.name + ".lrk_x.to_qk");
-            qky = conv_same1(uy, l.qky, ACT_NONE, nullptr, nullptr, l.name + ".lrk_y.to_qk");
+            qkx = conv_same1(ux, l.qkx, ACT_NONE, nullptr, nullptr, l.name + ".lrk_x.to_qk", -1, false);
+            qky = conv_same1(uy, l.qky, ACT_NONE, nullptr, nullptr, l.name + ".lrk_y.to_qk", -1, false);
             free_t(ux); free_t(uy);
         }
         const size_t kx_off = arena.alloc((size_t)B * heads * H * H * 4), ky_off = arena.alloc((size_t)B * heads * W * W * 4);
@@ -664,32 +673,32 @@ struct Planner {
         TRef out;
         if (can_fuse_1x1(e->packs[l.out1], e->packs[l.out3])) {
             // to_out.1 (512 -> 64, GELU) and to_out.3 (64 -> 64) + skip in ONE kernel
-            out = conv_same1(uphi, l.out1, ACT_GELU, &x, nullptr, l.name + ".to_out.1+3", l.out3);
+            out = conv_same1(uphi, l.out1, ACT_GELU, &x, nullptr, l.name + ".to_out.1+3", l.out3, raw_out);
             free_t(uphi);
         } else {
             TRef t1 = conv_same1(uphi, l.out1, ACT_GELU, nullptr, nullptr, l.name + ".to_out.1");
             free_t(uphi);
-            out = conv_same1(t1, l.out3, ACT_NONE, &x, nullptr, l.name + ".to_out.3");
+            out = conv_same1(t1, l.out3, ACT_NONE, &x, nullptr, l.name + ".to_out.3", -1, raw_out);
             free_t(t1);
         }
         return out;
     }
 
     // DilatedResidualBlock: train_stage2_ns2d.py:25-53
-    TRef lower_propblock(const Layer& l, TRef x) {
+    TRef lower_propblock(const Layer& l, TRef x, bool raw_out) {
         TRef xin = x; xin.owned = false;
         emit_gn(xin, 1, 1e-5f, l.p_g1, l.p_b1, 0, l.name + ".conv.0");
         TRef h1 = conv_same3(xin, l.p_c1, 1, l.mode_y, l.mode_x, ACT_GELU, nullptr, 0, l.name + ".conv.1");
         free_t(xin);
         TRef h2 = conv_same3(h1, l.p_c3, l.dil, l.mode_y, l.mode_x, ACT_GELU, nullptr, 0, l.name + ".conv.3");
         free_t(h1);
-        TRef x1 = conv_same3(h2, l.p_c5, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, l.name + ".conv.5");
+        TRef x1 = conv_same3(h2, l.p_c5, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, l.name + ".conv.5", false);
         free_t(h2);
         TRef xin2 = x1; xin2.owned = false;
         emit_gn(xin2, 1, 1e-5f, l.p_g2, l.p_b2, 0, l.name + ".ffn.0");
         TRef f1 = conv_same1(xin2, l.p_f1, ACT_GELU, nullptr, nullptr, l.name + ".ffn.1");
         free_t(xin2);
-        TRef out = conv_same1(f1, l.p_f3, ACT_NONE, &x1, nullptr, l.name + ".ffn.3");
+        TRef out = conv_same1(f1, l.p_f3, ACT_NONE, &x1, nullptr, l.name + ".ffn.3", -1, raw_out);
         free_t(f1); free_t(x1);
         return out;
     }
@@ -750,7 +759,7 @@ struct Planner {
     }
 
     // conditional DilatedResidualBlock: train_stage2_twophase_conditional.py:25-75
-    TRef lower_condblock(const Layer& l, TRef x) {
+    TRef lower_condblock(const Layer& l, TRef x, bool raw_out) {
         const lns_config& c = e->cfg;
         const int D = l.C, E = c.cond_emb_dim;
         const std::string q = l.name;
@@ -774,18 +783,18 @@ struct Planner {
         emit_gn(xin, 1, 1e-5f, l.p_g1, l.p_b1, 0, q + ".conv1.0");
         TRef h1 = conv_same3(xin, l.p_c1, 1, l.mode_y, l.mode_x, ACT_GELU, nullptr, 0, q + ".conv1.1");
         free_t(xin);
-        TRef h2 = conv_same3(h1, l.p_c3, l.dil, l.mode_y, l.mode_x, ACT_NONE, nullptr, tag(SP_WS, emb_off), q + ".conv1.3");
+        TRef h2 = conv_same3(h1, l.p_c3, l.dil, l.mode_y, l.mode_x, ACT_NONE, nullptr, tag(SP_WS, emb_off), q + ".conv1.3", false);
         free_t(h1);
         emit_gn(h2, 1, 1e-5f, l.c_g, l.c_b, 0, q + ".cond_conv1.0");
         TRef h3 = emit_apply(h2, ACT_GELU, q + ".cond_conv1.1");
         free_t(h2);
-        TRef x1 = conv_same3(h3, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2");
+        TRef x1 = conv_same3(h3, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2", false);
         free_t(h3);
         TRef xin2 = x1; xin2.owned = false;
         emit_gn(xin2, 1, 1e-5f, l.p_g2, l.p_b2, tag(SP_WS, mul_off), q + ".ffn.0");
         TRef f1 = conv_same1(xin2, l.p_f1, ACT_GELU, nullptr, nullptr, q + ".ffn.1");
         free_t(xin2);
-        TRef out = conv_same1(f1, l.p_f3, ACT_NONE, &x1, nullptr, q + ".ffn.3");
+        TRef out = conv_same1(f1, l.p_f3, ACT_NONE, &x1, nullptr, q + ".ffn.3", -1, raw_out);
         free_t(f1); free_t(x1);
         // emb / mul (and cond_ce) are never released: they depend on `param` only, so the steps after the first one
         // of a rollout reuse them (Runner::skip_step_invariant) and nothing else may be placed there
@@ -793,12 +802,12 @@ struct Planner {
     }
 
     // FourierBasicBlock: x + gelu(SpectralConv2d(x) + conv1x1(x))   modules/basics.py:574-583
-    TRef lower_fourier(const Layer& l, TRef x, const TRef* out_forced) {
+    TRef lower_fourier(const Layer& l, TRef x, const TRef* out_forced, bool raw_out) {
         if (x.pending()) throw std::runtime_error("FourierBasicBlock input must be materialised");
         if (l.cin != x.C || l.cin != l.cout) throw std::runtime_error("FourierBasicBlock needs in == out channels: " + l.name);
         const int C = x.C, H = x.H, W = x.W, m1 = l.m1, m2 = l.m2;
         if (2 * m1 > H || m2 > W / 2 + 1) throw std::runtime_error("too many Fourier modes for this resolution: " + l.name);
-        TRef x2 = conv_same1(x, l.f_conv, ACT_NONE, nullptr, nullptr, l.name + ".conv");
+        TRef x2 = conv_same1(x, l.f_conv, ACT_NONE, nullptr, nullptr, l.name + ".conv", -1, false);
         TRef x1 = alloc_t(C, H, W);
         const size_t t1 = arena.alloc((size_t)B * C * H * m2 * 2 * 4), xf = arena.alloc((size_t)B * C * 2 * m1 * m2 * 2 * 4),
                      of = arena.alloc((size_t)B * C * 2 * m1 * m2 * 2 * 4);
@@ -822,7 +831,8 @@ struct Planner {
             op.fc.a = as_ptr<const float>(x1.ptr); op.fc.b = as_ptr<const float>(x2.ptr); op.fc.e = nullptr;
             op.fc.skip = as_ptr<const float>(x.ptr); op.fc.skip_bs = x.bs; op.fc.y = as_ptr<float>(out.ptr);
             op.fc.y_bs = out.bs; op.fc.B = B; op.fc.C = C; op.fc.HW = H * W;
-            out.amax = new_amax(l.name + ".combine"); out.amax_const = 0.0f; op.fc.amax_out = as_ptr<unsigned>(out.amax);
+            out.amax = 0; out.amax_const = 0.0f; out.gn_bound = 0.0f; op.fc.amax_out = nullptr;
+            if (raw_out && !out_forced) { out.amax = new_amax(l.name + ".combine"); op.fc.amax_out = as_ptr<unsigned>(out.amax); }
             plan->ops.push_back(op);
         }
         free_t(x1); free_t(x2);
@@ -830,11 +840,21 @@ struct Planner {
     }
 
     // sequential program ---------------------------------------------------------
+    // does layer j read its input un-normalised through a (possibly split-operand) convolution?
+    static bool reads_raw(const std::vector<Layer>& L, size_t j) {
+        if (j >= L.size()) return false;                       // the program's output
+        switch (L[j].type) {
+            case LT_CONV: case LT_UP2: case LT_RESIZE: case LT_FOURIER: return true;
+            case LT_RES: return L[j].chup >= 0;
+            default: return false;                             // GroupNorm / LayerNorm first (GN, SA, FA, propagator blocks), Swish
+        }
+    }
     void lower_sequence(const std::vector<Layer>& L, TRef in, const TRef& out_ext) {
         TRef cur = in;
         for (size_t i = 0; i < L.size(); ++i) {
             const Layer& l = L[i];
             const bool last = (i + 1 == L.size());
+            const bool raw_next = reads_raw(L, i + 1);
             TRef nxt;
             switch (l.type) {
                 case LT_CONV: {
@@ -848,7 +868,8 @@ struct Planner {
                              can_fuse_1x1(e->packs[l.pack], e->packs[L[i + 1].pack])) { fuse = L[i + 1].pack; skip = 1; }
                     const bool is_last = (i + 1 + skip == L.size());
                     nxt = emit_conv(cur, l.pack, l.k, l.stride, l.dil, l.pad, l.mode_y, l.mode_x, act_out, nullptr, 0,
-                                    is_last ? &out_ext : nullptr, fuse >= 0 ? L[i + 1].name : l.name, fuse);
+                                    is_last ? &out_ext : nullptr, fuse >= 0 ? L[i + 1].name : l.name, fuse,
+                                    reads_raw(L, i + 1 + skip));
                     free_t(cur);
                     i += skip;
                     if (!is_last) trace(fuse >= 0 ? L[i].name : l.name, nxt);   // i already points at the fused 1x1
@@ -869,14 +890,14 @@ struct Planner {
                     if (cur.pending()) throw std::runtime_error("resize of a pending tensor");
                     if (l.outH != cur.H || l.outW != cur.W) { cur.vH = l.outH; cur.vW = l.outW; cur.sch = 0; cur.scw = 0; }
                     continue;
-                case LT_RES: nxt = lower_res(l, cur); free_t(cur); trace(l.name, nxt); break;
-                case LT_SA: nxt = lower_sa(l, cur); free_t(cur); trace(l.name, nxt); break;
-                case LT_FA: nxt = lower_fa(l, cur); free_t(cur); trace(l.name, nxt); break;
-                case LT_PROPBLOCK: nxt = lower_propblock(l, cur); free_t(cur); trace(l.name, nxt); break;
+                case LT_RES: nxt = lower_res(l, cur, raw_next); free_t(cur); trace(l.name, nxt); break;
+                case LT_SA: nxt = lower_sa(l, cur, raw_next); free_t(cur); trace(l.name, nxt); break;
+                case LT_FA: nxt = lower_fa(l, cur, raw_next); free_t(cur); trace(l.name, nxt); break;
+                case LT_PROPBLOCK: nxt = lower_propblock(l, cur, raw_next); free_t(cur); trace(l.name, nxt); break;
                 case LT_CONDBLOCK:
                     if (!cond_ce_live) emit_cond_base();
-                    nxt = lower_condblock(l, cur); free_t(cur); trace(l.name, nxt); break;
-                case LT_FOURIER: nxt = lower_fourier(l, cur, nullptr); free_t(cur); trace(l.name, nxt); break;
+                    nxt = lower_condblock(l, cur, raw_next); free_t(cur); trace(l.name, nxt); break;
+                case LT_FOURIER: nxt = lower_fourier(l, cur, nullptr, raw_next); free_t(cur); trace(l.name, nxt); break;
                 default: throw std::runtime_error("layer type not supported by this build: " + l.name);
             }
             if (last && l.type != LT_CONV) throw std::runtime_error("program must end in a convolution");
@@ -1777,7 +1798,7 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     const int rc = op_conv_prepare(oc, x, B, Cin, Hin, Win, Hv, Wv, w_host, bias_host, Cout, ksize, stride, dilation, pad_t,
                                    pad_b, pad_l, pad_r, mode_y, mode_x, ss, act_in, act_out, residual, badd, y, tile_variant);
     if (rc) { oc.release(); return rc; }
-    oc.a.amax_out = amax_out;
+    oc.a.amax_out = oc.variant == CV_THIN ? nullptr : amax_out;   // the thin final projection records none
     hipStream_t s = static_cast<hipStream_t>(stream);
     OPCHK(launch_conv(oc.variant, oc.a, s));
     OPCHK(hipStreamSynchronize(s));

@@ -59,6 +59,9 @@ struct ConvArgs {
     // stays normal for every element within 2^-17 of the sample's maximum.
     const unsigned* amax_in;
     float amax_in_const;
+    // 1: amax_in_const already bounds the TRANSFORMED input (a GroupNorm output: |gamma| sqrt(n_group) + |beta|, a
+    // function of the layer only), the kernel uses it as is -- no per-sample maximum, no reduction in the prologue
+    int bound_final;
     unsigned* amax_out;    // [B] or null: atomic max of the bit patterns of |y| over everything this launch stores
 };
 // power-of-two activation scale from a bound on |x| (host mirror of the device rule; tests)

@@ -104,12 +104,12 @@ __device__ __forceinline__ void amax_publish(unsigned* slot, unsigned local) {
     const unsigned m = wave_umax(local);
     if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
 }
-// S = 2^(CONVF_TARGET_EXP - e) for bound = m 2^e (1 <= m < 2), clamped to [2^-100, 2^60]; inv = 1 / S.
-// Non-finite bound (exponent field 255): S = 2^-100 and the staged values stay non-finite -> NaN results, as in fp32.
+// S = 2^(CONVF_TARGET_EXP - e) for bound = m 2^e (1 <= m < 2), clamped to [2^-110, 2^120]; inv = 1 / S.
+// Non-finite bound (exponent field 255): S = 2^-110 and the staged values stay non-finite -> NaN results, as in fp32.
 __device__ __forceinline__ float f16x2_scale(unsigned bound_bits, float& inv) {
     const int eb = (int)((bound_bits >> 23) & 0xffu);
     int f = 127 + CONVF_TARGET_EXP + 127 - eb;
-    f = f < 27 ? 27 : (f > 187 ? 187 : f);
+    f = f < 17 ? 17 : (f > 247 ? 247 : f);
     inv = __uint_as_float((unsigned)(254 - f) << 23);
     return __uint_as_float((unsigned)f << 23);
 }
@@ -118,6 +118,14 @@ __device__ __forceinline__ float f16x2_scale(unsigned bound_bits, float& inv) {
 // wmax[wave] (4 words of LDS); after the block's next barrier block_bound() gives the block-wide value.
 __device__ __forceinline__ void stage_ss_bound(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid, int nthr) {
     const bool has_ss = a.ss != nullptr;
+    if (a.bound_final) {                                   // the bound is a launch constant: only stage the table
+        for (int c = tid; c < a.Cin_pad; c += nthr) {
+            float2 st = make_float2(1.0f, 0.0f);
+            if (has_ss && c < a.Cin) st = *reinterpret_cast<const float2*>(a.ss + ((long)b * a.Cin + c) * 2);
+            *reinterpret_cast<float2*>(ssl + 2 * c) = st;
+        }
+        return;
+    }
     const float amax = a.amax_in ? __uint_as_float(a.amax_in[b]) : a.amax_in_const;
     unsigned loc = 0u;
     for (int c = tid; c < a.Cin_pad; c += nthr) {
@@ -129,7 +137,10 @@ __device__ __forceinline__ void stage_ss_bound(const ConvArgs& a, int b, float* 
     loc = wave_umax(loc);
     if ((tid & 63) == 0) wmax[tid >> 6] = loc;
 }
-__device__ __forceinline__ unsigned block_bound(const unsigned* wmax) { return max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); }
+__device__ __forceinline__ unsigned block_bound(const ConvArgs& a, const unsigned* wmax) {
+    if (a.bound_final) return __float_as_uint(a.amax_in_const);
+    return max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+}
 
 // block-wide sum for blockDim.x == 256 (4 waves); red must hold >= 4 floats
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
@@ -696,7 +707,7 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 template <int NT, bool FUSE2, int MT = 2>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
-                                               float unscale, const float* addv = nullptr) {
+                                               float xinv, const float* addv = nullptr) {
     constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
     static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
     f32x16 acc[MT][NT];
@@ -705,7 +716,8 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r]) * unscale;   // power of two
+            for (int r = 0; r < 16; ++r)      // two powers of two (1 / weight scale, 1 / activation scale), applied one after
+                acc[mt][nt][r] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r]) * a.unscale) * xinv;   // the other: no intermediate underflow
     const int HWo = a.Hout * a.Wout;
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
@@ -826,7 +838,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 for (int r = 0; r < 16; ++r) tm = max(tm, abs_bits(acc[mt][nt][r]));
             float inv2;
             const float s2 = f16x2_scale(wave_umax(tm), inv2);
-            const float unscale2 = inv2 / a.w2scale;                  // powers of two
+            const float w2inv = 1.0f / a.w2scale;                     // powers of two
             f32x16 a2h[MT], a2l[MT];
 #pragma unroll
             for (int m2 = 0; m2 < MT; ++m2)
@@ -856,7 +868,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             for (int m2 = 0; m2 < MT; ++m2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[m2][nt][r] = (a2h[m2][r] + a2l[m2][r]) * unscale2 + b2s[m2 * 32 + drow(r, kh)];
+                    acc[m2][nt][r] = ((a2h[m2][r] + a2l[m2][r]) * w2inv) * inv2 + b2s[m2 * 32 + drow(r, kh)];
         }
     }
     // GroupNorm statistics of the stored tile (planner: only when the 128-pixel tiles cover the plane exactly, so
@@ -978,11 +990,13 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             sy[u] = a.rowmap[ty * BH * a.stride + py];
             sx[u] = a.colmap[tx * BW * a.stride + px];
         }
-        stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
+        float addreg = 0.0f;                                    // requested before the bound reduction waits on its loads
         if (tid < TM) {
             const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
-            addv[tid] = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
+            addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
         }
+        stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
+        if (tid < TM) addv[tid] = addreg;
         if (tid < 4) reinterpret_cast<unsigned*>(zunit)[tid] = 0u;
         // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or none.
         // Threads past the end of the patch stage into the sink unit, so the K loop has no branches.
@@ -999,7 +1013,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // fp16 split: activations are staged multiplied by the sample's power-of-two scale (bf16x3 needs none)
     float xinv = 1.0f;
     if (SPL == 2) {
-        const float xs = f16x2_scale(block_bound(wmax), xinv);
+        const float xs = f16x2_scale(block_bound(a, wmax), xinv);
 #pragma unroll
         for (int u = 0; u < NU; ++u) uok[u] *= xs;
     }
@@ -1204,7 +1218,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
         pix[nt] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : -1;
     }
-    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, a.unscale * xinv,
+    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv,
                                   (a.bias || a.badd) ? addv : nullptr);
 }
 
@@ -1243,10 +1257,14 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
     const bool has_ss = a.ss != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
 
-    stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
-    if (tid < TM) {
-        const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
-        addv[tid] = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
+    {
+        float addreg = 0.0f;
+        if (tid < TM) {
+            const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
+            addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
+        }
+        stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
+        if (tid < TM) addv[tid] = addreg;
     }
     // (the barrier that publishes ssl / addv sits behind the first stage's global loads in k_loop: one memory
     //  latency before the first split instead of two)
@@ -1345,7 +1363,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         for (int i = 0; i < NWU; ++i) load_w(i, 0);
         __syncthreads();                                   // ssl / addv / wmax visible
         if (SPL == 2) {
-            const float xs = f16x2_scale(block_bound(wmax), xinv);
+            const float xs = f16x2_scale(block_bound(a, wmax), xinv);
 #pragma unroll
             for (int u = 0; u < NU; ++u) uok[u] *= xs;
         }
@@ -1436,7 +1454,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         const int p = p0 + wn * 32 + l31;
         pix[0] = p < a.Hout * a.Wout ? p : -1;
     }
-    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, a.unscale * xinv, (a.bias || a.badd) ? addv : nullptr);
+    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, (a.bias || a.badd) ? addv : nullptr);
 }
 
 // Input-stationary form of the 1x1 kernel for narrow inputs (Cin_pad <= 64) feeding many output channels:
@@ -1500,7 +1518,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
             if (st == 0) {
                 __syncthreads();                            // ssl / wmax visible (behind the first stage's global loads)
                 if (SPL == 2) {
-                    const float xs = f16x2_scale(block_bound(wmax), xinv);
+                    const float xs = f16x2_scale(block_bound(a, wmax), xinv);
 #pragma unroll
                     for (int u = 0; u < NU; ++u) uok[u] *= xs;
                 }
@@ -1621,7 +1639,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
         }
         __syncthreads();
         if (++st == nstage) {
-            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, a.unscale * xinv);
+            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, xinv);
             st = 0;
             ++ctl;
         }
@@ -1772,7 +1790,7 @@ float convf_scale_for_bound(float bound) {
     uint32_t u;
     __builtin_memcpy(&u, &bound, 4);
     int f = 127 + CONVF_TARGET_EXP + 127 - (int)((u >> 23) & 0xffu);
-    f = f < 27 ? 27 : (f > 187 ? 187 : f);
+    f = f < 17 ? 17 : (f > 247 ? 247 : f);
     const uint32_t sb = (uint32_t)f << 23;
     float sc;
     __builtin_memcpy(&sc, &sb, 4);
@@ -1925,20 +1943,11 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
         if (co < CO)
             *reinterpret_cast<float4*>(yb + (long)co * HW) = make_float4(acc[co][0] + bv[co], acc[co][1] + bv[co], acc[co][2] + bv[co], acc[co][3] + bv[co]);
     }
-    if (a.amax_out) {                                          // lanes that returned early simply do not take part
-        unsigned am = 0u;
-#pragma unroll
-        for (int co = 0; co < 4; ++co)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (co < CO) am = max(am, abs_bits(acc[co][e] + bv[co]));
-        atomicMax(a.amax_out + b, am);
-    }
 }
 
 bool conv1_thin_fits(const ConvArgs& a) {
     return a.ks == 1 && a.stride == 1 && a.Cout <= 4 && a.Cin <= 512 && ((a.Hin * a.Win) % 4) == 0 && !a.res && !a.badd &&
-           a.act_out == ACT_NONE && !a.w2 && (a.act_in == ACT_NONE || a.act_in == ACT_SWISH) && (a.x_bs % 4) == 0 &&
+           a.act_out == ACT_NONE && !a.w2 && !a.amax_out && (a.act_in == ACT_NONE || a.act_in == ACT_SWISH) && (a.x_bs % 4) == 0 &&
            (a.y_bs % 4) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y)) & 15) == 0;
 }
 

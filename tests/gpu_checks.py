@@ -97,9 +97,10 @@ def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), u
     out = y.cpu().numpy()
     assert np.isfinite(out).all(), "non-finite / unwritten outputs"
     # amax side channel: bit pattern of max |y| per sample, exactly
-    got = amax.cpu().numpy().view(np.float32)
-    want = np.abs(out).reshape(B, -1).max(1)
-    assert np.array_equal(got, want), ("amax side channel", got, want)
+    if variant != 12:       # (the thin final projection records none)
+        got = amax.cpu().numpy().view(np.float32)
+        want = np.abs(out).reshape(B, -1).max(1)
+        assert np.array_equal(got, want), ("amax side channel", got, want)
     # every sample on its own (samples of one batch may differ by orders of magnitude)
     err = max(rel_l2(out[i], ref[i]) for i in range(B))
     if fp64:

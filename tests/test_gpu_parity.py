@@ -65,12 +65,14 @@ def test_split_operand_domain(idx, case):
 
 
 def test_split_operand_extremes():
-    """Beyond the clamp of the dynamic scale (|x| ~ 1e-25: the low fp16 term is subnormal) the kernels degrade
-    gracefully -- finite, ~1e-5 accurate -- and a non-finite input gives non-finite outputs and a non-finite amax
-    (loud, as in fp32), never a silently wrong field."""
+    """Full accuracy down to |x| ~ 1e-25; at the edge of fp32's own range (1e-33, beyond the clamp of the dynamic
+    scale) the kernels degrade gracefully; a non-finite input gives non-finite outputs and a non-finite amax (loud,
+    as in fp32), never a silently wrong field."""
     _need_gpu()
     import gpu_checks as gc
     err, _ = gc.conv_case(B=2, Cin=64, Cout=64, H=16, W=16, k=3, variant=11, xscale=1e-25, bias=False, seed=7)
+    assert err < KERNEL_TOL
+    err, _ = gc.conv_case(B=2, Cin=64, Cout=64, H=16, W=16, k=1, variant=7, xscale=1e-33, bias=False, seed=8)
     assert err < 1e-3
     assert gc.conv_nonfinite_case()
 

@@ -187,8 +187,8 @@ int lns_timing_info(const lns_engine* e, int index, char* name, int name_capacit
  * x [B,Cin,Hin,Win] optionally nearest-resized to (Hv,Wv) before padding;
  * w [Cout,Cin,k,k] HOST pointer; ss [B,Cin,2] device (scale,shift) or NULL;
  * act: 0 none, 1 swish, 2 gelu.  tile_variant <0 = automatic.
- * amax_out (device, [B] unsigned, zero-initialised by the caller, or NULL): receives per sample the IEEE bit pattern of
- * max |y| -- the side channel from which the split-operand (f16x2) kernels of a plan derive their per-sample
+ * amax_out (device, [B][16] unsigned, zero-initialised by the caller, or NULL): the maximum over the 16 words of
+ * sample b is the IEEE bit pattern of max |y[b]| -- the side channel from which the split-operand (f16x2) kernels of a plan derive their per-sample
  * power-of-two activation scale.  The entry point computes the same quantity for x itself before the launch. */
 int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv,
                   const float* w_host, const float* bias_host, int Cout, int ksize, int stride,

@@ -293,16 +293,16 @@ struct Planner {
     }
 
     // amax slots: one [B] unsigned vector per produced tensor, all in one region taken before any op (never aliased)
-    enum { AMAX_SLOTS = 768 };
+    enum { AMAX_SLOTS = 256 };
     size_t amax_off = 0; int amax_used = 0;
     void init_amax_region() {
-        amax_off = arena.alloc((size_t)AMAX_SLOTS * B * 4);
+        amax_off = arena.alloc((size_t)AMAX_SLOTS * B * LNS_AMAX_SUB * 4);
         plan->amax_off = amax_off;
     }
     uint64_t new_amax(const std::string& name) {
         if (amax_used >= AMAX_SLOTS) throw std::runtime_error("amax slots exhausted at " + name);
         plan->amax_names.push_back(name);
-        return tag(SP_WS, amax_off + (size_t)(amax_used++) * B * 4);
+        return tag(SP_WS, amax_off + (size_t)(amax_used++) * B * LNS_AMAX_SUB * 4);
     }
     float vec_absmax(int id) const {
         if (id < 0) return 0.0f;
@@ -454,7 +454,10 @@ struct Planner {
         a.ks = k; a.stride = stride; a.dil = dil;
         a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / pk.wscale : 1.0f;   // x 1/S in the kernel
         if (in.ss != 0 && in.gn_bound > 0.0f) { a.amax_in_const = in.gn_bound; a.bound_final = 1; }   // GroupNorm output: layer constant
-        else { a.amax_in = as_ptr<const unsigned>(in.amax); a.amax_in_const = in.amax_const; }
+        else {
+            a.amax_in = as_ptr<const unsigned>(in.amax); a.amax_in_const = in.amax_const;
+            if (!in.amax && in.ss == 0) a.bound_final = 1;     // analytic bound of a raw tensor (LayerNorm / InstanceNorm output)
+        }
         out.amax = 0; out.amax_const = 0.0f; out.gn_bound = 0.0f;
         if (want_amax && !out_forced && g.variant != CV_THIN) { out.amax = new_amax(name); a.amax_out = as_ptr<unsigned>(out.amax); }
         a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.sel_kc_log2;
@@ -923,7 +926,7 @@ struct Planner {
             if (op.type == OP_CONDBASE) rebase(op.cb.freqs);
         }
         plan->arena_bytes = arena.high;
-        plan->amax_bytes = (size_t)amax_used * B * 4;
+        plan->amax_bytes = (size_t)amax_used * B * LNS_AMAX_SUB * 4;
     }
 };
 
@@ -1648,8 +1651,9 @@ int lns_check_finite(lns_engine* e, int B, void* ws, size_t ws_bytes, void* stre
             host.resize(p.amax_bytes / 4);
             HIPCHK(e, hipMemcpy(host.data(), arena + p.amax_off, p.amax_bytes, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < p.amax_names.size(); ++i)
-                for (int b = 0; b < B; ++b)
-                    if (((host[i * B + b] >> 23) & 0xffu) == 0xffu) {
+                for (int bk = 0; bk < B * LNS_AMAX_SUB; ++bk)
+                    if (((host[i * B * LNS_AMAX_SUB + bk] >> 23) & 0xffu) == 0xffu) {
+                        const int b = bk / LNS_AMAX_SUB;
                         e->err = fmt("non-finite values in the output of %s (%s, sample %d)", p.amax_names[i].c_str(), what, b);
                         return LNS_ENONFINITE;
                     }
@@ -1774,8 +1778,8 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
     a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / wscale : 1.0f;
     // the input's per-sample maximum, as the producing kernel of a plan would have recorded it
-    OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.damax), (size_t)B * 4));
-    OPCHK(hipMemset(oc.damax, 0, (size_t)B * 4));
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.damax), (size_t)B * LNS_AMAX_SUB * 4));
+    OPCHK(hipMemset(oc.damax, 0, (size_t)B * LNS_AMAX_SUB * 4));
     OPCHK(launch_amax(x, a.x_bs, (long)Cin * Hin * Win, B, oc.damax, nullptr));
     OPCHK(hipStreamSynchronize(nullptr));
     a.amax_in = oc.damax;

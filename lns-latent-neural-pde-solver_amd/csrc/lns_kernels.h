@@ -57,6 +57,9 @@ struct ConvArgs {
     // bound = max_c(|scale_c| amax + |shift_c|) (or amax without a prologue) and stages activations multiplied by the
     // power of two S that puts `bound` in [2^14, 2^15): no fixed input range, fp16 never overflows, and the low term
     // stays normal for every element within 2^-17 of the sample's maximum.
+    // Layout of every amax vector: [B][LNS_AMAX_SUB] -- same-address atomics cost ~0.3 us each at the memory side, so a
+    // block publishes ONE value into sub-slot (blockIdx.x % LNS_AMAX_SUB) of its sample and the consumer takes the
+    // maximum of the 16 words (one 64-byte scalar load).
     const unsigned* amax_in;
     float amax_in_const;
     // 1: amax_in_const already bounds the TRANSFORMED input (a GroupNorm output: |gamma| sqrt(n_group) + |beta|, a
@@ -86,6 +89,7 @@ hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 // bound * S lies in [2^14, 2^15), the fp16 range (65504) is never reached and the absolute error of an element's
 // two-term representation is <= max(2^-22 |x|, 2^-39 bound).  S is clamped to [2^-100, 2^60].
 #define CONVF_TARGET_EXP 14
+#define LNS_AMAX_SUB 16
 #define CONVB_SLAB_BYTES 27648           // one (cout tile, stage) weight slab: 3 splits x 9 taps x 64 couts x 8 ch bf16
 size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits);
 bool convb_fits(const ConvArgs& a);
@@ -232,7 +236,7 @@ hipError_t launch_metric_rel_l2_ch(const float* yhat, const float* y, int B, int
                                    const MetricChannelSpec& spec, float eps, float* frame_out, float* seq_out,
                                    float* scratch, hipStream_t s);
 
-// per-sample max |x| (bit patterns) of a [B, n] tensor with batch stride x_bs: amax[b] = max(amax[b], ...)
+// per-sample max |x| (bit patterns) of a [B, n] tensor with batch stride x_bs into amax [B][LNS_AMAX_SUB] (atomic max)
 hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax, hipStream_t s);
 
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU

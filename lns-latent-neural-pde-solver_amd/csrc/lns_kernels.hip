@@ -99,10 +99,24 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
     const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
     return max(max(r0, r1), max(r2, r3));
 }
-// one atomic per wave; called by whole waves
-__device__ __forceinline__ void amax_publish(unsigned* slot, unsigned local) {
+// amax vectors are [B][LNS_AMAX_SUB]: reader side
+__device__ __forceinline__ unsigned amax_load(const unsigned* amax, int b) {
+    const unsigned* p = amax + (long)b * LNS_AMAX_SUB;
+    unsigned m = 0u;
+#pragma unroll
+    for (int k = 0; k < LNS_AMAX_SUB; ++k) m = max(m, p[k]);
+    return m;
+}
+// writer side, one atomic per 256-thread BLOCK through 4 words of LDS nobody else touches any more; called by all
+// threads of the block at a converged point
+__device__ __forceinline__ void amax_publish_block(unsigned* amax, int b, unsigned local, unsigned* red4) {
     const unsigned m = wave_umax(local);
-    if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bm = max(max(red4[0], red4[1]), max(red4[2], red4[3]));
+        if (bm) atomicMax(amax + (long)b * LNS_AMAX_SUB + (blockIdx.x & (LNS_AMAX_SUB - 1)), bm);
+    }
 }
 // S = 2^(CONVF_TARGET_EXP - e) for bound = m 2^e (1 <= m < 2), clamped to [2^-110, 2^120]; inv = 1 / S.
 // Non-finite bound (exponent field 255): S = 2^-110 and the staged values stay non-finite -> NaN results, as in fp32.
@@ -126,7 +140,7 @@ __device__ __forceinline__ void stage_ss_bound(const ConvArgs& a, int b, float* 
         }
         return;
     }
-    const float amax = a.amax_in ? __uint_as_float(a.amax_in[b]) : a.amax_in_const;
+    const float amax = a.amax_in ? __uint_as_float(amax_load(a.amax_in, b)) : a.amax_in_const;
     unsigned loc = 0u;
     for (int c = tid; c < a.Cin_pad; c += nthr) {
         float2 st = make_float2(1.0f, 0.0f);
@@ -561,7 +575,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
             }
         }
     }
-    if (a.amax_out) amax_publish(a.amax_out + b, am);
+    if (a.amax_out) {                                  // block-uniform
+        __syncthreads();                               // every wave is done with the stage buffers
+        amax_publish_block(a.amax_out, b, am, reinterpret_cast<unsigned*>(lds));
+    }
 }
 
 static const ConvVariantInfo kConvInfo[CV_COUNT] = {
@@ -707,7 +724,7 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 template <int NT, bool FUSE2, int MT = 2>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
-                                               float xinv, const float* addv = nullptr) {
+                                               float xinv, unsigned& am, const float* addv = nullptr) {
     constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
     static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
     f32x16 acc[MT][NT];
@@ -878,7 +895,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     const bool stats = NT == 1 && MT == 2 && a.stat_part != nullptr;     // block-uniform
     float* sb = reinterpret_cast<float*>(lds);
     if (stats) __syncthreads();                                  // main-loop / fused-conv LDS reads are done
-    unsigned am = 0u;                                            // amax side channel: bit pattern of max |stored value|
+    // (am: amax side channel, bit pattern of max |stored value|; the calling kernel publishes it once per block)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if (pix[nt] < 0) continue;
@@ -900,7 +917,6 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             }
         }
     }
-    if (a.amax_out) amax_publish(a.amax_out + b, am);
     if (stats) {
         __syncthreads();
         const int c = tid >> 2, q = tid & 3;
@@ -990,13 +1006,6 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             sy[u] = a.rowmap[ty * BH * a.stride + py];
             sx[u] = a.colmap[tx * BW * a.stride + px];
         }
-        float addreg = 0.0f;                                    // requested before the bound reduction waits on its loads
-        if (tid < TM) {
-            const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
-            addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
-        }
-        stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
-        if (tid < TM) addv[tid] = addreg;
         if (tid < 4) reinterpret_cast<unsigned*>(zunit)[tid] = 0u;
         // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or none.
         // Threads past the end of the patch stage into the sink unit, so the K loop has no branches.
@@ -1005,18 +1014,13 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             const int p = tid + u * NTHR;
             const bool ok = p < PLANE && sy[u] >= 0 && sx[u] >= 0;
             udm[u] = ok ? sy[u] * a.Win + sx[u] : 0;
-            uok[u] = ok ? 1.0f : 0.0f;
+            uok[u] = ok ? 1.0f : 0.0f;                          // times the activation scale once the bound is known
             uslot[u] = (p < PLANE ? p : PLANE) * 16;
         }
     }
-    __syncthreads();
-    // fp16 split: activations are staged multiplied by the sample's power-of-two scale (bf16x3 needs none)
+    // (the scale/shift table, the add vector and the activation bound are staged inside k_loop, BEHIND the first
+    //  stage's patch and weight loads: their memory latencies overlap, and the barrier that publishes them comes after)
     float xinv = 1.0f;
-    if (SPL == 2) {
-        const float xs = f16x2_scale(block_bound(a, wmax), xinv);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) uok[u] *= xs;
-    }
     // weight slab of this cout tile: host slabs hold 64 couts per (split, tap) row; a 32-cout block copies its half
     // of every row.  16 bytes per thread-slot.
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * SLAB64 +
@@ -1127,6 +1131,21 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             for (int cp = 0; cp < 4; ++cp) load_pair(u, cp, 0);
 #pragma unroll
         for (int i = 0; i < NWU; ++i) load_w(i, 0);
+        {
+            float addreg = 0.0f;
+            if (tid < TM) {
+                const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
+                addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
+            }
+            stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
+            if (tid < TM) addv[tid] = addreg;
+        }
+        __syncthreads();                                   // ssl / addv / wmax / zunit visible
+        if (SPL == 2) {   // fp16 split: activations are staged multiplied by the sample's power-of-two scale
+            const float xs = f16x2_scale(block_bound(a, wmax), xinv);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) uok[u] *= xs;
+        }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -1218,8 +1237,10 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
         pix[nt] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : -1;
     }
-    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv,
+    unsigned am = 0u;
+    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am,
                                   (a.bias || a.badd) ? addv : nullptr);
+    if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);    // wmax: free since the prologue
 }
 
 // ===========================================================================
@@ -1257,17 +1278,8 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
     const bool has_ss = a.ss != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
 
-    {
-        float addreg = 0.0f;
-        if (tid < TM) {
-            const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
-            addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
-        }
-        stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
-        if (tid < TM) addv[tid] = addreg;
-    }
-    // (the barrier that publishes ssl / addv sits behind the first stage's global loads in k_loop: one memory
-    //  latency before the first split instead of two)
+    // (ssl / addv / the activation bound are staged in k_loop behind the first stage's global loads, and the barrier
+    //  that publishes them comes after: one memory latency before the first split instead of two)
 
     // two staging units (pixel, octet) per thread.  VEC2 (even H*W): two adjacent pixels of one octet, fetched
     // with 8-byte loads; otherwise one pixel, octets o and o + 2.
@@ -1361,6 +1373,15 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         for (int cp = 0; cp < 4; ++cp) load_pairs(cp, 0);
 #pragma unroll
         for (int i = 0; i < NWU; ++i) load_w(i, 0);
+        {
+            float addreg = 0.0f;
+            if (tid < TM) {
+                const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
+                addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
+            }
+            stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
+            if (tid < TM) addv[tid] = addreg;
+        }
         __syncthreads();                                   // ssl / addv / wmax visible
         if (SPL == 2) {
             const float xs = f16x2_scale(block_bound(a, wmax), xinv);
@@ -1454,7 +1475,9 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         const int p = p0 + wn * 32 + l31;
         pix[0] = p < a.Hout * a.Wout ? p : -1;
     }
-    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, (a.bias || a.badd) ? addv : nullptr);
+    unsigned am = 0u;
+    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am, (a.bias || a.badd) ? addv : nullptr);
+    if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);
 }
 
 // Input-stationary form of the 1x1 kernel for narrow inputs (Cin_pad <= 64) feeding many output channels:
@@ -1484,7 +1507,6 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
     const float* xb = a.x + (long)b * a.x_bs;
     const bool has_ss = a.ss != nullptr;
 
-    stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
     float xinv = 1.0f;
 
     // ---- stage the whole pixel tile (all channels) ----------------------------------
@@ -1516,7 +1538,8 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
                 }
             }
             if (st == 0) {
-                __syncthreads();                            // ssl / wmax visible (behind the first stage's global loads)
+                stage_ss_bound(a, b, ssl, wmax, tid, NTHR);  // behind the first stage's global loads
+                __syncthreads();                            // ssl / wmax visible
                 if (SPL == 2) {
                     const float xs = f16x2_scale(block_bound(a, wmax), xinv);
 #pragma unroll
@@ -1579,6 +1602,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
         pix[0] = p < a.Hout * a.Wout ? p : -1;
     }
     int st = 0, ctl = 0;
+    unsigned am = 0u;
     for (int it = 0; it < nit; ++it) {
         if (st == 0) {
 #pragma unroll
@@ -1639,11 +1663,12 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
         }
         __syncthreads();
         if (++st == nstage) {
-            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, xinv);
+            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, xinv, am);
             st = 0;
             ++ctl;
         }
     }
+    if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);    // once per block, over all its cout tiles
 }
 
 size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 64 * 4 + 16 + 16; }
@@ -2477,7 +2502,7 @@ __global__ __launch_bounds__(256) void fa_reducer_kernel(FaReducerArgs a) {
         if (row < a.rows) {
             const long bi = row / a.n, i = row - bi * a.n;
             a.u[(bi * Out + o) * a.n + i] = acc;
-            if (a.amax_out) atomicMax(a.amax_out + bi, abs_bits(acc));
+            if (a.amax_out) atomicMax(a.amax_out + bi * LNS_AMAX_SUB + (idx & (LNS_AMAX_SUB - 1)), abs_bits(acc));
         }
     }
 }
@@ -2614,11 +2639,12 @@ __device__ __forceinline__ void fa_reducer_mfma_body(const FaReducerArgs& a, int
         // a block's 32 rows usually belong to one sample: one atomic per wave; otherwise one per lane
         const long bi0 = __builtin_amdgcn_readfirstlane((int)bi);
         const bool live = row < a.rows;
+        const int sub = block & (LNS_AMAX_SUB - 1);
         if (__all((!live || bi == bi0) ? 1 : 0)) {
             const unsigned m = wave_umax(live ? am_u : 0u);
-            if (lane == 0 && m) atomicMax(a.amax_out + bi0, m);
+            if (lane == 0 && m) atomicMax(a.amax_out + bi0 * LNS_AMAX_SUB + sub, m);
         } else if (live) {
-            atomicMax(a.amax_out + bi, am_u);
+            atomicMax(a.amax_out + bi * LNS_AMAX_SUB + sub, am_u);
         }
     }
     if (a.qk) {                                            // fused to_qk: qk[m][r] = sum_o wqk[o][m] * X3[o][r] (+ bias)
@@ -3350,7 +3376,7 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs a) {
         ys[i] = v;
         am = max(am, abs_bits(v));
     }
-    if (a.amax_out) amax_publish(a.amax_out + b, am);
+    if (a.amax_out) { __shared__ unsigned red4[4]; amax_publish_block(a.amax_out, b, am, red4); }
 }
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(apply_kernel, dim3(a.C, a.B), dim3(256), 0, s, a);
@@ -3494,7 +3520,7 @@ __global__ __launch_bounds__(256) void fourier_combine_kernel(FourierCombineArgs
         ys[i] = v;
         am = max(am, abs_bits(v));
     }
-    if (a.amax_out) amax_publish(a.amax_out + b, am);
+    if (a.amax_out) { __shared__ unsigned red4[4]; amax_publish_block(a.amax_out, b, am, red4); }
 }
 hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(fourier_combine_kernel, dim3(a.C, a.B), dim3(256), 0, s, a);
@@ -3614,7 +3640,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* x, long x_bs, lo
     const float* xs = x + (long)b * x_bs;
     unsigned am = 0u;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) am = max(am, abs_bits(xs[i]));
-    amax_publish(amax + b, am);
+    __shared__ unsigned red4[4];
+    amax_publish_block(amax, b, am, red4);
 }
 hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax, hipStream_t s) {
     long chunks = (n + 256 * 16 - 1) / (256 * 16);

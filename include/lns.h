@@ -127,6 +127,17 @@ int lns_set_weight(lns_engine* e, const char* key, const float* host_data,
 /* Repack all weights into kernel-native layout and upload to HIP device `device`. */
 int lns_finalize_weights(lns_engine* e, int device);
 
+/* Scheduling options of the rollout (they change HOW the launch sets are issued, never a bit of the result):
+ *   "decode_group"    steps decoded by one launch set at batch B * k (default 1; 0 = automatic: about 256 samples per
+ *                     launch set.  Measured on NS2d-128 B=64: k = 4 cuts the serial kernel time 11 % and the launches
+ *                     2x but the overlapped rollout is 2 % slower than k = 1, tools/sched_sweep.py)
+ *   "decode_streams"  decode streams of the overlapped rollout (1..4)
+ *   "overlap"         1: latent chain on a side stream, decodes round-robin on the decode streams; 0: one stream
+ *   "prop_priority"   1: the side stream of the latent chain is created with the highest stream priority
+ * Defaults come from LNS_DECODE_GROUP / LNS_DECODE_STREAMS / LNS_NO_OVERLAP / LNS_PROP_PRIORITY at lns_create().
+ * Changing an option changes the workspace size: call lns_prepare() again. */
+int lns_set_option(lns_engine* e, const char* name, long value);
+
 /* Latent shape for the configured field size: z is [B, C, H, W]. */
 int lns_latent_shape(const lns_engine* e, int* C, int* H, int* W);
 

@@ -58,7 +58,7 @@ class LnsConfig(ctypes.Structure):
 SYMBOLS = [
     "lns_create_error", "lns_create", "lns_destroy", "lns_last_error", "lns_num_params",
     "lns_param_info", "lns_set_weight", "lns_finalize_weights", "lns_latent_shape", "lns_prepare",
-    "lns_encode", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite",
+    "lns_encode", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite", "lns_set_option",
     "lns_trace_enable", "lns_trace_count", "lns_trace_info", "lns_trace_copy",
     "lns_timing_enable", "lns_timing_count", "lns_timing_info",
     "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block", "lns_metric_rel_l2", "lns_metric_rel_l2_ch",
@@ -111,6 +111,8 @@ def lib():
     L.lns_rollout_latent.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, c.c_size_t, vp]
     if hasattr(L, "lns_check_finite"):      # (absent from older builds loaded through LNS_HIP_LIB for A/B runs)
         L.lns_check_finite.argtypes = [vp, i, vp, c.c_size_t, vp]
+    if hasattr(L, "lns_set_option"):
+        L.lns_set_option.argtypes = [vp, c.c_char_p, c.c_long]
     L.lns_trace_enable.argtypes = [vp, i]
     L.lns_trace_count.argtypes = [vp]
     L.lns_trace_info.argtypes = [vp, i, c.c_char_p, i, i64p]

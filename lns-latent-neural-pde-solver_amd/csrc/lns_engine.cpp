@@ -14,6 +14,9 @@
 
 #include "lns_engine.h"
 
+// the batch is a grid dimension (gridDim.y / .z) of every kernel
+#define LNS_MAX_BATCH 65535
+
 namespace lns {
 void build_model(lns_engine* e);
 
@@ -45,7 +48,7 @@ static size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 static inline uint64_t tag(int space, size_t byte_off) { return ((uint64_t)space << 56) | (uint64_t)byte_off; }
 template <class T> static inline T* as_ptr(uint64_t t) { return reinterpret_cast<T*>(t); }
 
-struct Bases { char* b[16]; long bs[16]; mutable bool bad = false; };
+struct Bases { char* b[16]; long bs[16]; long bs2[16]; int bdiv[16]; mutable bool bad = false; };
 template <class T> static inline void fix(T*& p, const Bases& B) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     if (!v) return;
@@ -1096,10 +1099,14 @@ struct Runner {
         B.b[SP_CT] = static_cast<char*>(plan.d_consts);
         for (int i = 0; i < EX_COUNT; ++i) {
             B.b[SP_EXT0 + i] = const_cast<char*>(static_cast<const char*>(ext[i].ptr));
-            B.bs[SP_EXT0 + i] = ext[i].bs;
+            B.bs[SP_EXT0 + i] = ext[i].bs; B.bs2[SP_EXT0 + i] = ext[i].bs2; B.bdiv[SP_EXT0 + i] = ext[i].bdiv;
         }
         // the amax side channel accumulates with atomic max: every run of the plan starts from zero
         if (plan.amax_bytes) HIPCHK(e, hipMemsetAsync(arena_base + plan.amax_off, 0, plan.amax_bytes, stream));
+        {
+            const std::pair<const Plan*, char*> key(&plan, arena_base);
+            if (std::find(e->ran.begin(), e->ran.end(), key) == e->ran.end()) e->ran.push_back(key);
+        }
         for (const Op& op : plan.ops) {
             if (skip_step_invariant && (op.type == OP_CONDBASE || op.type == OP_CONDBLK)) continue;
             EvPair ev;
@@ -1126,6 +1133,11 @@ struct Runner {
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
                     fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B); fix(a.stat_part, B);
                     fix(a.amax_in, B); fix(a.amax_out, B);
+                    if (a.y_bs < 0) {          // output handed in by the caller: may be addressed in two levels (step-batched decode)
+                        const int sl = SP_EXT0 + (int)(-a.y_bs - 1);
+                        a.y_bs2 = B.bs2[sl]; a.y_bdiv = B.bdiv[sl];
+                    }
+                    if (a.x_bs < 0 && B.bdiv[SP_EXT0 + (int)(-a.x_bs - 1)]) B.bad = true;   // inputs are always plain
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
                     if (!all_untagged(a.x, a.w, a.bias, a.ss, a.rowmap, a.colmap, a.y, a.res, a.badd, a.w2, a.bias2, a.wb, a.stat_part,
                                       a.amax_in, a.amax_out)) B.bad = true;
@@ -1268,30 +1280,48 @@ struct Runner {
     }
 };
 
-// workspace layout: [ z ping | z pong | arena ]
-// workspace layout: [ z ring (ZRING latents) | arena A (encode / decode plans) | arena B (propagator plan) ]
+// workspace layout: [ z0 | latent ring: NGROUP groups x kdec steps x [B][zper] | NDEC decode arenas | propagator arena ]
 // The propagator gets its own arena because it runs on a second stream, concurrently with decode.
-enum { ZRING = 6, NDEC = 4 };   // latents in flight; max decode streams (steps round-robin)
-struct WsLayout { size_t z_bytes, arena_off, arena_stride, prop_off, total; int ndec; };
+// Step-batched decode: the decodes of different steps are independent given z_t, so the latent chain runs ahead and
+// `kdec` consecutive steps are decoded by ONE launch set at batch B * kdec (4x the blocks per launch on the 16x16 /
+// 32x32 decoder layers, a quarter of the launches, weight slabs amortised).  A trajectory-step's arithmetic does not
+// depend on the batch it rides in (kernel accumulation order is a function of the layer only), so the result is
+// bit-identical for every kdec.
+enum { NDEC = 4, NGROUP_MAX = NDEC + 2 };   // max decode streams; latent groups in flight
+struct WsLayout { size_t z_bytes, ring_off, group_bytes, arena_off, arena_stride, prop_off, total; int ndec, kdec, ngroup; };
+
+static int decode_group(const lns_engine* e, int B) {
+    // trajectories x steps per decode launch set: about 256 samples ("decode_group" option; 1 = one step per launch)
+    int k = e->opt_decode_group > 0 ? e->opt_decode_group : std::max(1, 256 / std::max(1, B));
+    k = std::min(k, 8);
+    while (k > 1 && (long)B * k > LNS_MAX_BATCH) --k;
+    return k;
+}
 
 static int ws_layout(lns_engine* e, int B, WsLayout* L) {
     size_t arena = 0, parena = 0;
     Plan* p;
     int rc;
+    L->kdec = decode_group(e, B);
     if (!e->enc.empty()) {
         if ((rc = get_plan(e, PK_ENC, B, 0, 0, &p))) return rc;
         arena = std::max(arena, p->arena_bytes);
-        if ((rc = get_plan(e, PK_DEC, B, 0, 0, &p))) return rc;
-        arena = std::max(arena, p->arena_bytes);
+        for (int kk = 1; kk <= L->kdec; ++kk) {           // a rollout's last group may hold fewer steps
+            if ((rc = get_plan(e, PK_DEC, B * kk, 0, 0, &p))) return rc;
+            arena = std::max(arena, p->arena_bytes);
+        }
     }
     if (!e->prop.empty() && e->lat_H > 0) {
         if ((rc = get_plan(e, PK_PROP, B, e->lat_H, e->lat_W, &p))) return rc;
         parena = p->arena_bytes;
     }
-    L->z_bytes = round_up_sz((size_t)B * std::max(1, e->lat_C) * std::max(1, e->lat_H) * std::max(1, e->lat_W) * 4, 256);
-    static const int ndec_env = getenv("LNS_DECODE_STREAMS") ? atoi(getenv("LNS_DECODE_STREAMS")) : 3;
-    L->ndec = std::min((int)NDEC, std::max(1, ndec_env));
-    L->arena_off = ZRING * L->z_bytes;
+    const size_t zper = (size_t)std::max(1, e->lat_C) * std::max(1, e->lat_H) * std::max(1, e->lat_W);
+    L->z_bytes = round_up_sz((size_t)B * zper * 4, 256);
+    L->ndec = std::min((int)NDEC, std::max(1, e->opt_decode_streams));
+    L->ngroup = L->ndec + 2;                                           // one being written, one per decode stream, one spare
+    L->group_bytes = (size_t)L->kdec * B * zper * 4;                   // steps of a group are contiguous: [kdec][B][zper]
+    L->ring_off = L->z_bytes;
+    L->arena_off = round_up_sz(L->ring_off + (size_t)L->ngroup * L->group_bytes, 256);
     L->arena_stride = round_up_sz(arena, 256);                        // one decode arena per decode stream
     L->prop_off = L->arena_off + (size_t)L->ndec * L->arena_stride;
     L->total = L->prop_off + round_up_sz(parena, 256) + 256;
@@ -1301,13 +1331,19 @@ static int ws_layout(lns_engine* e, int B, WsLayout* L) {
 // second stream + events for the propagate / decode overlap (created once, owned by the engine)
 static int ensure_overlap_objects(lns_engine* e) {
     if (e->side_stream) return LNS_OK;
-    HIPCHK(e, hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&e->side_stream), hipStreamNonBlocking));
+    if (e->opt_prop_priority) {
+        int lo = 0, hi = 0;                                   // numerically lower = higher priority
+        HIPCHK(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(e, hipStreamCreateWithPriority(reinterpret_cast<hipStream_t*>(&e->side_stream), hipStreamNonBlocking, hi));
+    } else {
+        HIPCHK(e, hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&e->side_stream), hipStreamNonBlocking));
+    }
     for (int i = 0; i < NDEC - 1; ++i) {
         hipStream_t st;
         HIPCHK(e, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         e->dec_streams.push_back(st);
     }
-    for (int i = 0; i < 2 * ZRING + 1 + NDEC; ++i) {
+    for (int i = 0; i < 2 * NGROUP_MAX + 1 + NDEC; ++i) {
         hipEvent_t ev;
         HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         e->events.push_back(ev);
@@ -1343,6 +1379,10 @@ int lns_create(const lns_config* cfg, lns_engine** out) {
     if (cfg->abi_version != LNS_ABI_VERSION) { g_create_error = "ABI version mismatch"; return LNS_EINVAL; }
     lns_engine* e = new lns_engine();
     e->cfg = *cfg;
+    if (const char* v = getenv("LNS_DECODE_GROUP")) e->opt_decode_group = atoi(v);
+    if (const char* v = getenv("LNS_DECODE_STREAMS")) e->opt_decode_streams = atoi(v);
+    if (getenv("LNS_NO_OVERLAP")) e->opt_overlap = 0;
+    if (getenv("LNS_PROP_PRIORITY")) e->opt_prop_priority = 1;
     e->cfg.ae_prefix[sizeof(e->cfg.ae_prefix) - 1] = 0;
     e->cfg.prop_prefix[sizeof(e->cfg.prop_prefix) - 1] = 0;
     try {
@@ -1401,6 +1441,19 @@ int lns_finalize_weights(lns_engine* e, int device) {
     return finalize_weights(e, device);
 }
 
+int lns_set_option(lns_engine* e, const char* name, long value) {
+    if (!e || !name) return LNS_EINVAL;
+    const std::string n = name;
+    if (n == "decode_group") { if (value < 0 || value > 8) return LNS_EINVAL; e->opt_decode_group = (int)value; }
+    else if (n == "decode_streams") { if (value < 1 || value > NDEC) return LNS_EINVAL; e->opt_decode_streams = (int)value; }
+    else if (n == "overlap") e->opt_overlap = value != 0;
+    else if (n == "prop_priority") {
+        if (e->opt_prop_priority != (value != 0)) { DeviceGuard dg(e); release_overlap_objects(e); }   // recreated with the new priority
+        e->opt_prop_priority = value != 0;
+    } else { e->err = "unknown option: " + n; return LNS_EINVAL; }
+    return LNS_OK;
+}
+
 int lns_latent_shape(const lns_engine* e, int* C, int* H, int* W) {
     if (!e || e->enc.empty()) return LNS_EINVAL;
     if (C) *C = e->lat_C;
@@ -1409,8 +1462,7 @@ int lns_latent_shape(const lns_engine* e, int* C, int* H, int* W) {
     return LNS_OK;
 }
 
-// the batch is a grid dimension (gridDim.y / .z) of every kernel
-#define LNS_MAX_BATCH 65535
+// the batch is a grid dimension of every kernel (LNS_MAX_BATCH)
 static int check_batch(lns_engine* e, int B) {
     if (B > LNS_MAX_BATCH) { e->err = fmt("batch %d exceeds the maximum of %d trajectories per call", B, LNS_MAX_BATCH); return LNS_EINVAL; }
     return LNS_OK;
@@ -1445,6 +1497,7 @@ int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t 
     ext[EX_IN] = {x, (long)c.in_channels * c.Ly * c.Lx};
     ext[EX_OUT] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
     Runner r(e, static_cast<hipStream_t>(stream));
+    e->ran.clear();
     if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
     return r.finish();
 }
@@ -1462,6 +1515,7 @@ int lns_decode(lns_engine* e, const float* z, int B, float* y, void* ws, size_t 
     ext[EX_IN] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
     ext[EX_OUT] = {y, (long)c.in_channels * c.Ly * c.Lx};
     Runner r(e, static_cast<hipStream_t>(stream));
+    e->ran.clear();
     if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
     return r.finish();
 }
@@ -1481,21 +1535,22 @@ int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, i
     ext[EX_OUT] = {z_out, per};
     ext[EX_PARAM] = {param, 1};
     Runner r(e, static_cast<hipStream_t>(stream));
+    e->ran.clear();
     if ((rc = r.run(*p, ext, static_cast<char*>(ws)))) return rc;
     return r.finish();
 }
 
 // shared autoregressive loop: zcur -> T x (propagate ; decode)   (train_stage2_ns2d.py:147-156)
-// The latent chain z_t -> z_{t+1} is strictly sequential, but decode(z_t) depends on z_t only:
-// with to_x the propagator chain runs on the engine's side stream (own arena, ring of ZRING
-// latents) and the decodes on the caller's stream, ordered by events, so the small latent-resolution
-// kernels of step t+1 overlap the large decode kernels of step t.
+// The latent chain z_t -> z_{t+1} is strictly sequential, but decode(z_t) depends on z_t only: the chain runs ahead
+// (on the engine's side stream when overlapping; own arena) writing groups of `kdec` consecutive latents into the
+// ring, and every finished group is decoded by one launch set at batch B * kdec on one of the decode streams
+// (round-robin, one arena each), ordered by events, so the small latent-resolution kernels of later steps overlap
+// the large decode kernels of earlier ones.
 static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param, int B, int T, int to_x, float* out,
                         float* latents_out, float* z_last, const WsLayout& L, char* base) {
-    Plan *pp, *pd;
+    Plan* pp;
     int rc;
     if ((rc = get_plan(e, PK_PROP, B, e->lat_H, e->lat_W, &pp))) return rc;
-    if ((rc = get_plan(e, PK_DEC, B, 0, 0, &pd))) return rc;
     const lns_config& c = e->cfg;
     const long zper = (long)e->lat_C * e->lat_H * e->lat_W;
     const long xper = (long)c.in_channels * c.Ly * c.Lx;
@@ -1504,30 +1559,19 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
     hipStream_t stream = r.stream;
     ExtT ext[EX_COUNT];
     ext[EX_PARAM] = {param, 1};
-    static const bool no_overlap = getenv("LNS_NO_OVERLAP") != nullptr;
-    const bool overlap = to_x && !latents_out && !e->trace_on && !e->timing_on && !no_overlap;
-    if (!overlap) {
-        // single-stream path (latent-only rollouts, diagnostics)
-        int slot = 1;
+    if (!to_x) {
+        // latent-only rollout: single stream, latents written straight into the output
         for (int t = 0; t < T; ++t) {   // strictly sequential in t, independent in b
-            ExtT znext;
-            if (latents_out) znext = {latents_out + (long)t * zper, (long)T * zper};
-            else if (!to_x) znext = {out + (long)t * zper, (long)T * zper};
-            else { znext = {base + (size_t)slot * L.z_bytes, zper}; slot = slot % (ZRING - 1) + 1; }
+            ExtT znext = {out + (long)t * zper, (long)T * zper};
             ext[EX_IN] = zcur;
             ext[EX_OUT] = znext;
             r.skip_step_invariant = t > 0 && !e->trace_on;
             rc = r.run(*pp, ext, parena);
             r.skip_step_invariant = false;
             if (rc) return rc;
-            if (to_x) {
-                ext[EX_IN] = znext;
-                ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
-                if ((rc = r.run(*pd, ext, arena))) return rc;
-            } else if (latents_out) {
-                HIPCHK(e, hipMemcpy2DAsync(out + (long)t * zper, (size_t)T * zper * 4, znext.ptr, (size_t)T * zper * 4,
+            if (latents_out)
+                HIPCHK(e, hipMemcpy2DAsync(latents_out + (long)t * zper, (size_t)T * zper * 4, znext.ptr, (size_t)T * zper * 4,
                                            (size_t)zper * 4, B, hipMemcpyDeviceToDevice, stream));
-            }
             zcur = znext;
         }
         if (z_last)
@@ -1535,60 +1579,76 @@ static int rollout_loop(lns_engine* e, Runner& r, ExtT zcur, const float* param,
                                        hipMemcpyDeviceToDevice, stream));
         return LNS_OK;
     }
-    if ((rc = ensure_overlap_objects(e))) return rc;
-    hipStream_t pstream = static_cast<hipStream_t>(e->side_stream);
-    // decodes of different steps are independent too: step t runs on decode stream t % ndec
-    // (stream 0 = the caller's), each with its own arena
-    const int ndec = L.ndec;
+    const bool overlap = !e->trace_on && !e->timing_on && e->opt_overlap;
+    const int kdec = e->trace_on ? 1 : L.kdec, ngroup = L.ngroup, ndec = overlap ? L.ndec : 1;
+    if (overlap && (rc = ensure_overlap_objects(e))) return rc;
+    hipStream_t pstream = overlap ? static_cast<hipStream_t>(e->side_stream) : stream;
     hipStream_t dstream[NDEC];
     char* darena[NDEC];
     std::vector<Runner> rd;
     for (int d = 0; d < ndec; ++d) {
         dstream[d] = d == 0 ? stream : e->dec_streams[d - 1];
         darena[d] = arena + (size_t)d * L.arena_stride;
-        rd.emplace_back(e, dstream[d]);
+        if (overlap) rd.emplace_back(e, dstream[d]);
     }
-    Runner rp(e, pstream);
-    hipEvent_t* ev_z = e->events.data();             // ev_z[s]: latent in ring slot s is complete
-    hipEvent_t* ev_free = e->events.data() + ZRING;  // ev_free[s]: decode has finished reading ring slot s
-    hipEvent_t ev_start = e->events[2 * ZRING];
-    hipEvent_t* ev_end = e->events.data() + 2 * ZRING + 1;   // [0]: propagator stream, [d]: decode stream d
-    // ring slot 0 is never written by the loop (it may hold the caller's / encoder's z0)
-    HIPCHK(e, hipEventRecord(ev_start, stream));
-    HIPCHK(e, hipStreamWaitEvent(pstream, ev_start, 0));
-    for (int d = 1; d < ndec; ++d) HIPCHK(e, hipStreamWaitEvent(dstream[d], ev_start, 0));
-    int slot = 1;
-    std::vector<char> used(ZRING, 0);
-    for (int t = 0; t < T; ++t) {
-        const int s = slot;
-        slot = slot % (ZRING - 1) + 1;              // 1, 2, ..., ZRING-1, 1, ...
-        ExtT znext = {base + (size_t)s * L.z_bytes, zper};
-        if (used[s]) HIPCHK(e, hipStreamWaitEvent(pstream, ev_free[s], 0));   // WAR: decode(t - (ZRING-1)) done
-        ext[EX_IN] = zcur;
-        ext[EX_OUT] = znext;
-        rp.skip_step_invariant = t > 0;
-        if ((rc = rp.run(*pp, ext, parena))) return rc;
-        HIPCHK(e, hipEventRecord(ev_z[s], pstream));
-        const int d = t % ndec;
-        HIPCHK(e, hipStreamWaitEvent(dstream[d], ev_z[s], 0));
-        ext[EX_IN] = znext;
-        ext[EX_OUT] = {out + (long)t * xper, (long)T * xper};
-        if ((rc = rd[d].run(*pd, ext, darena[d]))) return rc;
-        HIPCHK(e, hipEventRecord(ev_free[s], dstream[d]));
-        used[s] = 1;
-        zcur = znext;
+    Runner rp_side(e, pstream);
+    Runner& rp = overlap ? rp_side : r;              // single-stream: everything through the caller's runner (timing events)
+    hipEvent_t *ev_z = nullptr, *ev_free = nullptr, *ev_end = nullptr;
+    if (overlap) {
+        ev_z = e->events.data();                     // ev_z[g]: the latents of ring group g are complete
+        ev_free = e->events.data() + NGROUP_MAX;     // ev_free[g]: the decode that read ring group g has finished
+        hipEvent_t ev_start = e->events[2 * NGROUP_MAX];
+        ev_end = e->events.data() + 2 * NGROUP_MAX + 1;   // [0]: propagator stream, [d]: decode stream d
+        HIPCHK(e, hipEventRecord(ev_start, stream));
+        HIPCHK(e, hipStreamWaitEvent(pstream, ev_start, 0));
+        for (int d = 1; d < ndec; ++d) HIPCHK(e, hipStreamWaitEvent(dstream[d], ev_start, 0));
     }
-    if (z_last) {
-        // the last latent is complete once the propagator stream has passed ev_z of its slot
+    char* ring = base + L.ring_off;
+    std::vector<char> used(ngroup, 0);
+    int g = 0, gi = 0;
+    for (int t = 0; t < T;) {
+        const int kk = std::min(kdec, T - t);
+        char* gbase = ring + (size_t)g * L.group_bytes;
+        if (overlap && used[g]) HIPCHK(e, hipStreamWaitEvent(pstream, ev_free[g], 0));   // WAR: the decode of the group that lived here
+        for (int j = 0; j < kk; ++j) {               // strictly sequential in t, independent in b
+            ExtT znext = {gbase + (size_t)j * B * zper * 4, zper};
+            ext[EX_IN] = zcur;
+            ext[EX_OUT] = znext;
+            rp.skip_step_invariant = (t + j) > 0 && !e->trace_on;
+            rc = rp.run(*pp, ext, parena);
+            rp.skip_step_invariant = false;
+            if (rc) return rc;
+            if (latents_out)
+                HIPCHK(e, hipMemcpy2DAsync(latents_out + (long)(t + j) * zper, (size_t)T * zper * 4, znext.ptr, (size_t)zper * 4,
+                                           (size_t)zper * 4, B, hipMemcpyDeviceToDevice, pstream));
+            zcur = znext;
+        }
+        // decode the group: launch sample s = j * B + b reads latent [j][b] and writes out[b][t + j]
+        Plan* pd;
+        if ((rc = get_plan(e, PK_DEC, B * kk, 0, 0, &pd))) return rc;
+        const int d = gi % ndec;
+        if (overlap) {
+            HIPCHK(e, hipEventRecord(ev_z[g], pstream));
+            HIPCHK(e, hipStreamWaitEvent(dstream[d], ev_z[g], 0));
+        }
+        ext[EX_IN] = {gbase, zper};
+        ext[EX_OUT] = {out + (long)t * xper, (long)T * xper, xper, B};
+        if ((rc = (overlap ? rd[d] : r).run(*pd, ext, darena[d]))) return rc;
+        if (overlap) { HIPCHK(e, hipEventRecord(ev_free[g], dstream[d])); used[g] = 1; }
+        t += kk;
+        g = (g + 1) % ngroup;
+        ++gi;
+    }
+    if (z_last)   // the last latent is complete once the propagator stream has passed its step
         HIPCHK(e, hipMemcpy2DAsync(z_last, (size_t)zper * 4, zcur.ptr, (size_t)zcur.bs * 4, (size_t)zper * 4, B,
                                    hipMemcpyDeviceToDevice, pstream));
-    }
-    // join: everything the side streams did is ordered before whatever the caller enqueues next
-    HIPCHK(e, hipEventRecord(ev_end[0], pstream));
-    HIPCHK(e, hipStreamWaitEvent(stream, ev_end[0], 0));
-    for (int d = 1; d < ndec; ++d) {
-        HIPCHK(e, hipEventRecord(ev_end[d], dstream[d]));
-        HIPCHK(e, hipStreamWaitEvent(stream, ev_end[d], 0));
+    if (overlap) {   // join: everything the side streams did is ordered before whatever the caller enqueues next
+        HIPCHK(e, hipEventRecord(ev_end[0], pstream));
+        HIPCHK(e, hipStreamWaitEvent(stream, ev_end[0], 0));
+        for (int d = 1; d < ndec; ++d) {
+            HIPCHK(e, hipEventRecord(ev_end[d], dstream[d]));
+            HIPCHK(e, hipStreamWaitEvent(stream, ev_end[d], 0));
+        }
     }
     return LNS_OK;
 }
@@ -1610,6 +1670,7 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
     Runner r(e, static_cast<hipStream_t>(stream));
     ExtT ext[EX_COUNT];
     ext[EX_PARAM] = {param, 1};
+    e->ran.clear();
     // encode once: x -> z0                                    (train_stage2_ns2d.py:144)
     ext[EX_IN] = {x, (long)c.in_channels * c.Ly * c.Lx};
     ext[EX_OUT] = {base, zper};
@@ -1629,6 +1690,7 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
     Runner r(e, static_cast<hipStream_t>(stream));
+    e->ran.clear();
     ExtT z0 = {z_in, (long)e->lat_C * e->lat_H * e->lat_W};
     if ((rc = rollout_loop(e, r, z0, param, B, T, to_x, out, nullptr, z_last, L, static_cast<char*>(ws)))) return rc;
     return r.finish();
@@ -1636,35 +1698,28 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
 
 int lns_check_finite(lns_engine* e, int B, void* ws, size_t ws_bytes, void* stream) {
     if (!e || B <= 0 || !ws) return LNS_EINVAL;
+    (void)ws_bytes;
     DeviceGuard dg(e);
     HIPCHK(e, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    const bool full = !e->enc.empty();
-    WsLayout L;
-    int rc;
-    if (full && ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes)))) return rc;
-    char* base = static_cast<char*>(ws);
     std::vector<unsigned> host;
-    auto scan = [&](const std::map<long, Plan>& plans, const char* what, char* arena) -> int {
-        for (const auto& kv : plans) {
-            const Plan& p = kv.second;
-            if (p.B != B || !p.amax_bytes) continue;
-            host.resize(p.amax_bytes / 4);
-            HIPCHK(e, hipMemcpy(host.data(), arena + p.amax_off, p.amax_bytes, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < p.amax_names.size(); ++i)
-                for (int bk = 0; bk < B * LNS_AMAX_SUB; ++bk)
-                    if (((host[i * B * LNS_AMAX_SUB + bk] >> 23) & 0xffu) == 0xffu) {
-                        const int b = bk / LNS_AMAX_SUB;
-                        e->err = fmt("non-finite values in the output of %s (%s, sample %d)", p.amax_names[i].c_str(), what, b);
-                        return LNS_ENONFINITE;
-                    }
-        }
-        return LNS_OK;
-    };
-    if (!full) return scan(e->prop_plans, "propagator", base);          // propagator-only engine: the arena is the workspace
-    if ((rc = scan(e->enc_plans, "encoder", base + L.arena_off))) return rc;
-    if ((rc = scan(e->prop_plans, "propagator", base + L.prop_off))) return rc;
-    for (int d = 0; d < L.ndec; ++d)
-        if ((rc = scan(e->dec_plans, "decoder", base + L.arena_off + (size_t)d * L.arena_stride))) return rc;
+    for (const auto& pr : e->ran) {                        // in the order the last call first ran them
+        const Plan& p = *pr.first;
+        if (!p.amax_bytes) continue;
+        host.resize(p.amax_bytes / 4);
+        HIPCHK(e, hipMemcpy(host.data(), pr.second + p.amax_off, p.amax_bytes, hipMemcpyDeviceToHost));
+        const char* what = "plan";
+        for (const auto& kv : e->enc_plans) if (&kv.second == &p) what = "encoder";
+        for (const auto& kv : e->dec_plans) if (&kv.second == &p) what = "decoder";
+        for (const auto& kv : e->prop_plans) if (&kv.second == &p) what = "propagator";
+        const size_t per = (size_t)p.B * LNS_AMAX_SUB;
+        for (size_t i = 0; i < p.amax_names.size(); ++i)
+            for (size_t bk = 0; bk < per; ++bk)
+                if (((host[i * per + bk] >> 23) & 0xffu) == 0xffu) {
+                    const int s = (int)(bk / LNS_AMAX_SUB);   // launch sample; step-batched decodes: s = step-in-group * B + trajectory
+                    e->err = fmt("non-finite values in the output of %s (%s, sample %d)", p.amax_names[i].c_str(), what, s % B);
+                    return LNS_ENONFINITE;
+                }
+    }
     return LNS_OK;
 }
 

@@ -111,7 +111,9 @@ struct Plan {
     std::vector<std::string> amax_names;
 };
 
-struct ExtT { const void* ptr = nullptr; long bs = 0; };
+// tensor handed in by the caller / the rollout loop: base, batch stride (floats) and, for step-batched launches, the
+// two-level form (sample s -> (s % bdiv) * bs + (s / bdiv) * bs2; bdiv 0: plain)
+struct ExtT { const void* ptr = nullptr; long bs = 0; long bs2 = 0; int bdiv = 0; };
 
 struct TraceRec { std::string name; int B, C, H, W; std::vector<float> data; };
 struct TimeRec { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
@@ -138,6 +140,13 @@ struct lns_engine {
     void* side_stream = nullptr;
     std::vector<hipStream_t> dec_streams;
     std::vector<hipEvent_t> events;
+    // scheduling options (lns_set_option; defaults from the LNS_* environment variables of the same meaning)
+    int opt_decode_group = 1;      // steps decoded per launch set; 0 = automatic (about 256 samples per launch set)
+    int opt_decode_streams = 3;
+    int opt_overlap = 1;           // propagator / decode streams; 0 = everything on the caller's stream
+    int opt_prop_priority = 0;     // 1: the propagator's side stream is created with the highest priority
+    // (plan, arena) pairs the last top-level call ran: lns_check_finite reads their amax vectors
+    std::vector<std::pair<const lns::Plan*, char*>> ran;
     // diagnostics
     bool trace_on = false;
     std::vector<lns::TraceRec> trace;

@@ -24,6 +24,9 @@ struct ConvArgs {
     const int* colmap;     // padded/virtual col  -> source col or -1
     float* y;              // [B, Cout, Hout, Wout], batch stride y_bs
     long y_bs;
+    // two-level batch addressing of y (step-batched decode: launch sample s = step j * y_bdiv + trajectory b writes
+    // out[b][t0 + j]): y + (s % y_bdiv) * y_bs + (s / y_bdiv) * y_bs2 when y_bdiv > 0
+    int y_bdiv; long y_bs2;
     int Cout, Hout, Wout;
     const float* res;      // residual, same shape as y (batch stride res_bs) or null
     long res_bs;

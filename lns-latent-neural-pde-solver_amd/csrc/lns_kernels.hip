@@ -156,6 +156,12 @@ __device__ __forceinline__ unsigned block_bound(const ConvArgs& a, const unsigne
     return max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
 }
 
+// batch base of the output tensor (two-level addressing for step-batched launches, see ConvArgs::y_bdiv)
+__device__ __forceinline__ float* y_base(const ConvArgs& a, int b) {
+    if (a.y_bdiv > 0) return a.y + (long)(b % a.y_bdiv) * a.y_bs + (long)(b / a.y_bdiv) * a.y_bs2;
+    return a.y + (long)b * a.y_bs;
+}
+
 // block-wide sum for blockDim.x == 256 (4 waves); red must hold >= 4 floats
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
 
     // ---- epilogue ---------------------------------------------------------------
     const int HWo = a.Hout * a.Wout;
-    float* yb = a.y + (long)b * a.y_bs;
+    float* yb = y_base(a, b);
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
     const bool full_co = (ct + 1) * TM <= a.Cout;   // no cout masking needed in this block
     if (a.bias || a.badd) {
@@ -736,7 +742,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             for (int r = 0; r < 16; ++r)      // two powers of two (1 / weight scale, 1 / activation scale), applied one after
                 acc[mt][nt][r] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r]) * a.unscale) * xinv;   // the other: no intermediate underflow
     const int HWo = a.Hout * a.Wout;
-    float* yb = a.y + (long)b * a.y_bs;
+    float* yb = y_base(a, b);
     const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
     // residual tile: all loads issued here, branch-free (clamped addresses), so their latency hides behind the
     // epilogue arithmetic instead of one round trip per stored element (y may alias nothing, but the compiler
@@ -1959,7 +1965,7 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
             }
         }
     }
-    float* yb = a.y + (long)b * a.y_bs + (long)p4 * 4;
+    float* yb = y_base(a, b) + (long)p4 * 4;
     float bv[4];                                               // bias loads ahead of the stores
 #pragma unroll
     for (int co = 0; co < 4; ++co) bv[co] = a.bias ? a.bias[co < CO ? co : 0] : 0.0f;
@@ -1973,7 +1979,7 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
 bool conv1_thin_fits(const ConvArgs& a) {
     return a.ks == 1 && a.stride == 1 && a.Cout <= 4 && a.Cin <= 512 && ((a.Hin * a.Win) % 4) == 0 && !a.res && !a.badd &&
            a.act_out == ACT_NONE && !a.w2 && !a.amax_out && (a.act_in == ACT_NONE || a.act_in == ACT_SWISH) && (a.x_bs % 4) == 0 &&
-           (a.y_bs % 4) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y)) & 15) == 0;
+           (a.y_bs % 4) == 0 && (a.y_bs2 % 4) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y)) & 15) == 0;
 }
 
 hipError_t launch_conv1_thin(const ConvArgs& a, hipStream_t s) {

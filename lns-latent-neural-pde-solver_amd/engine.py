@@ -159,6 +159,12 @@ class Engine:
         self.device_index = int(device_index)
         self._ws.clear()
 
+    def set_option(self, name, value):
+        """Scheduling options of the rollout (include/lns.h lns_set_option): decode_group, decode_streams, overlap,
+        prop_priority.  Results never depend on them."""
+        self._check(self._L.lns_set_option(self._h, name.encode(), int(value)), "lns_set_option")
+        self._ws.clear()                      # the workspace size depends on the options
+
     def latent_shape(self):
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self._check(self._L.lns_latent_shape(self._h, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)),

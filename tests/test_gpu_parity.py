@@ -293,13 +293,20 @@ def test_overlapped_rollout_equals_single_stream():
     x = filler.normal("xfull", (64, args.in_channels, args.Ly, args.Lx), 5)
     xd = torch.from_numpy(x).cuda()
     eng = model._engine(xd)
+    eng.set_option("decode_group", 1)
     eng.timing_enable(True)            # diagnostics mode = everything on the caller's stream
     ref = model.predict(xd, 6, to_x=True).clone()
     eng.timing_enable(False)
-    for _ in range(3):
-        y = model.predict(xd, 6, to_x=True)
-        torch.cuda.synchronize()
-        assert torch.equal(y, ref)
+    # scheduling options never change a bit: steps decoded per launch set (batch 64 * k, ragged last group: 6 = 4 + 2),
+    # number of decode streams, stream priority of the latent chain, single stream
+    for opts in (dict(decode_group=1), dict(decode_group=4), dict(decode_group=4, decode_streams=2, prop_priority=1),
+                 dict(decode_group=3, overlap=0), dict(decode_group=0), dict(decode_group=1, decode_streams=3, overlap=1, prop_priority=0)):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        for _ in range(2):
+            y = model.predict(xd, 6, to_x=True)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref), opts
 
 
 def test_full_size_rollout_properties():

@@ -92,6 +92,21 @@ def fill_state_dict(shapes: dict, seed: int) -> dict:
     return out
 
 
+def inv_freq(dim):
+    """RotaryEmbedding buffer (reference: modules/embedding.py:166): a constant, not a weight."""
+    return (1.0 / (10000 ** (np.arange(0, dim, 2, dtype=np.float32) / np.float32(dim)))).astype(np.float32)
+
+
+def synthetic_state_dict(shapes: dict, seed: int) -> dict:
+    """{key: ndarray} for a {key: shape} manifest: the deterministic filler for learned tensors, the analytic constant
+    for rotary `inv_freq` buffers."""
+    sd = fill_state_dict(shapes, seed)
+    for k, shp in shapes.items():
+        if k.endswith("inv_freq"):
+            sd[k] = inv_freq(2 * int(shp[0]))
+    return sd
+
+
 def load_into_torch_module(module, seed: int):
     """Overwrite a torch module's parameters/buffers in place with the
     deterministic filler (used on the reference model and on the drop-in)."""

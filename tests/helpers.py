@@ -41,19 +41,14 @@ def case_inputs(meta, args):
 
 
 def inv_freq(dim):
-    """RotaryEmbedding buffer (modules/embedding.py:166): a constant, not a weight."""
-    return (1.0 / (10000 ** (np.arange(0, dim, 2, dtype=np.float32) / np.float32(dim)))).astype(np.float32)
+    from lns_amd import filler
+    return filler.inv_freq(dim)
 
 
 def synthetic_state_dict(shapes, seed):
-    """{key: ndarray} for a {key: shape} manifest: deterministic filler for learned
-    tensors, the analytic constant for rotary inv_freq buffers."""
+    """{key: ndarray} for a {key: shape} manifest (lns_amd.filler.synthetic_state_dict)."""
     from lns_amd import filler
-    sd = filler.fill_state_dict(shapes, seed)
-    for k, shp in shapes.items():
-        if k.endswith("inv_freq"):
-            sd[k] = inv_freq(2 * int(shp[0]))
-    return sd
+    return filler.synthetic_state_dict(shapes, seed)
 
 
 # ---- SURVEY 8f-2: denormalise + relative-L2 metric fixtures (tests/golden/metrics.npz, tools/make_golden_metrics.py)

@@ -124,3 +124,33 @@ def test_shard_bounds_cover_the_batch():
     assert parallel.chunk_lengths(256, 8) == [128, 64, 32, 16, 8, 8]
     assert sum(parallel.chunk_lengths(37, 4)) == 37
     assert parallel.chunk_lengths(5, 2) == [2, 2, 1]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent makes no GPU call, starts two ranks
+    through torch.distributed.run, relays rank 0's JSON line and exits with the children's status.  CPU rehearsal:
+    gloo backend and --plumbing-only (sharding + step-block all-gather + barrier / max-over-ranks timing, no compute)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--plumbing-only", "--steps", "2", "--warmup", "1", "--batch", "3", "--rollout", "9",
+                        "--gather-chunk", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]           # ONE JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["plumbing_ok"] is True
+    assert rec["config"]["global_batch"] == 6 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert "overlapped all-gather" in rec["config"]["parallelism"]
+
+
+def test_bench_workload_labels_follow_the_preset():
+    """metric / workload strings are derived from the preset (they were hard-coded to NS2d in round 1)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for preset, (label, wl, fixtures) in bench.WORKLOADS.items():
+        assert label and wl
+        for T, fx in fixtures.items():
+            assert os.path.exists(os.path.join(ROOT, "tests", "golden", fx + ".npz")), fx
+    assert "NS2d" in bench.WORKLOADS["ns2d_128"][0] and "two-phase" in bench.WORKLOADS["twophase_cond"][0]

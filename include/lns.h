@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LNS_ABI_VERSION 1
+#define LNS_ABI_VERSION 2
 #define LNS_MAX_STAGES 8
 #define LNS_MAX_KEY 160
 
@@ -102,6 +102,10 @@ typedef struct lns_config {
     int32_t cond_emb_dim;           /* conditional propagator only */
     char ae_prefix[32];             /* state_dict prefix of the AE: "vq_ae." / "ae." / "" */
     char prop_prefix[32];           /* "propagator." / ""                                 */
+    /* ABI 2: ConditionalSimpleAutoencoder (modules/autoencoder2d_nonsquared.py:279-305): the encoder is CondEncoder
+     * (:71-145, CondResidualBlock modules/cond_utils.py:58-128) and encode takes `param`; LNS_AE_NONSQUARED only */
+    int32_t cond_encoder;
+    int32_t cond_emb_channels;
 } lns_config;
 
 typedef struct lns_engine lns_engine;
@@ -148,6 +152,9 @@ int lns_prepare(lns_engine* e, int B, size_t* workspace_bytes);
 /* SimpleAutoencoder.encode: x [B,Cin,Ly,Lx] -> z [B,latent_dim,h,w]. */
 int lns_encode(lns_engine* e, const float* x, int B, float* z,
                void* workspace, size_t workspace_bytes, void* stream);
+/* ConditionalSimpleAutoencoder.encode(x, param) (cfg.cond_encoder = 1): param [B] device, one value per sample. */
+int lns_encode_cond(lns_engine* e, const float* x, const float* param, int B, float* z,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* SimpleAutoencoder.decode: z [B,latent_dim,h,w] -> y [B,Cin,Ly,Lx]. */
 int lns_decode(lns_engine* e, const float* z, int B, float* y,
                void* workspace, size_t workspace_bytes, void* stream);
@@ -227,14 +234,17 @@ int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, 
 
 /* FourierBasicBlock (modules/basics.py:531-583) and CondFourierBasicBlock
  * (modules/fourier_cond.py:84-117) as standalone ops (not reached by any shipped config):
- *   y = x + gelu( irfft2(modes(rfft2(x)) . W{1,2} [* FreqLinear(cond)]) + conv1x1(x) [+ Linear(cond)] )
- * x,y [B,C,H,W] device; all weights HOST pointers in the reference's state_dict layout:
- *   w1,w2 [C,C,m1,m2,2]; conv_w [C,C,1,1], conv_b [C];
- *   conditional only (cond != NULL, device [B,C]): freq_w [C,4*m1*m2], freq_b [1,4*m1*m2], lin_w [C,C], lin_b [C]. */
-int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int m2, const float* w1_host,
+ *   y = [x +] act( irfft2(modes(rfft2(x)) . W{1,2} [* FreqLinear(cond)]) + conv1x1(x) [+ Linear(cond)] )
+ * x [B,Cin,H,W], y [B,Cout,H,W] device; all weights HOST pointers in the reference's state_dict layout:
+ *   w1,w2 [Cin,Cout,m1,m2,2]; conv_w [Cout,Cin,1,1], conv_b [Cout];
+ *   conditional only (cond != NULL, device [B,Cin]): freq_w [Cin,4*m1*m2], freq_b [1,4*m1*m2], lin_w [Cout,Cin], lin_b [Cout].
+ * activation: 1 silu, 2 gelu, 3 relu, 4 tanh, 5 sigmoid (ACTIVATION_REGISTRY, basics.py:10-16; the conditional block
+ * hard-codes GELU, fourier_cond.py:114); residual != 0 adds x (needs Cin == Cout, basics.py:581-582). */
+int lns_op_fourier_block(const float* x, int B, int Cin, int Cout, int H, int W, int m1, int m2, const float* w1_host,
                          const float* w2_host, const float* conv_w_host, const float* conv_b_host,
                          const float* cond, const float* freq_w_host, const float* freq_b_host,
-                         const float* lin_w_host, const float* lin_b_host, float* y, void* stream);
+                         const float* lin_w_host, const float* lin_b_host, int activation, int residual,
+                         float* y, void* stream);
 
 /* ---- "next row" (SURVEY 8f-2): the step right after the path -------------------------------------------------
  * Fused denormalise + relative-L2 metric of a decoded rollout against the ground truth, one pass over both tensors:

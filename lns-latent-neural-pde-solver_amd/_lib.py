@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("LNS_HIP_LIB") or os.path.join(_HERE, "liblns_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 LNS_MAX_STAGES = 8
-LNS_ABI_VERSION = 1
+LNS_ABI_VERSION = 2
 LNS_AE_NONE, LNS_AE_SQUARE, LNS_AE_NONSQUARED, LNS_AE_HALF_PERIODIC = 0, 1, 2, 3
 LNS_PROP_NONE, LNS_PROP_PLAIN, LNS_PROP_CONDITIONAL = 0, 1, 2
 LNS_PAD_ZEROS, LNS_PAD_CIRCULAR = 0, 1
@@ -51,6 +51,7 @@ class LnsConfig(ctypes.Structure):
         ("prop_n_block", _I32), ("prop_n_embd", _I32), ("prop_dilation", _I32),
         ("prop_pad_y", _I32), ("prop_pad_x", _I32), ("cond_emb_dim", _I32),
         ("ae_prefix", ctypes.c_char * 32), ("prop_prefix", ctypes.c_char * 32),
+        ("cond_encoder", _I32), ("cond_emb_channels", _I32),
     ]
 
 
@@ -58,7 +59,7 @@ class LnsConfig(ctypes.Structure):
 SYMBOLS = [
     "lns_create_error", "lns_create", "lns_destroy", "lns_last_error", "lns_num_params",
     "lns_param_info", "lns_set_weight", "lns_finalize_weights", "lns_latent_shape", "lns_prepare",
-    "lns_encode", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite", "lns_set_option",
+    "lns_encode", "lns_encode_cond", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite", "lns_set_option",
     "lns_trace_enable", "lns_trace_count", "lns_trace_info", "lns_trace_copy",
     "lns_timing_enable", "lns_timing_count", "lns_timing_info",
     "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block", "lns_metric_rel_l2", "lns_metric_rel_l2_ch",
@@ -106,6 +107,8 @@ def lib():
     L.lns_prepare.argtypes = [vp, i, c.POINTER(c.c_size_t)]
     L.lns_encode.argtypes = [vp, vp, i, vp, vp, c.c_size_t, vp]
     L.lns_decode.argtypes = [vp, vp, i, vp, vp, c.c_size_t, vp]
+    if hasattr(L, "lns_encode_cond"):
+        L.lns_encode_cond.argtypes = [vp, vp, vp, i, vp, vp, c.c_size_t, vp]
     L.lns_propagate.argtypes = [vp, vp, vp, i, i, i, vp, vp, c.c_size_t, vp]
     L.lns_rollout.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, c.c_size_t, vp]
     L.lns_rollout_latent.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, c.c_size_t, vp]
@@ -126,7 +129,7 @@ def lib():
     L.lns_op_groupnorm_stats.argtypes = [vp, i, i, i, i, c.c_float, vp, vp, vp, vp, vp]
     L.lns_op_attention.argtypes = [vp, i, i, i, i, c.c_float, vp, vp]
     L.lns_op_fa_sandwich.argtypes = [vp, vp, vp, i, i, i, i, i, c.c_float, i, vp, vp]
-    L.lns_op_fourier_block.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lns_op_fourier_block.argtypes = [vp, i, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp]
     L.lns_metric_rel_l2.argtypes = [vp, vp, i, i, i, i, c.c_float, c.c_float, c.c_float, vp, vp, vp, vp]
     L.lns_metric_rel_l2.restype = i
     L.lns_metric_rel_l2_ch.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp, c.c_float, c.c_float, c.c_float, vp, vp, vp, vp]

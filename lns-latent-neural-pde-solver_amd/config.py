@@ -62,6 +62,21 @@ PRESETS = {
                           is_periodic=False, cond_channels=1, cond_emb_channels=64,
                           attn_resolutions=[15, 30], decoder_attn_heads=8, decoder_attn_dim=64,
                           prop_n_block=4, dilation=2),
+    # ConditionalSimpleAutoencoder on the two-phase shape (modules/autoencoder2d_nonsquared.py:279-305; the keys
+    # cond_channels / cond_emb_channels are those of configs/twophase_stage2_cond_prop.yml:13-14)
+    "twophase_cond_ae": dict(_COMMON, family="twophase", latent_dim=64, Ly=61, Lx=121,
+                             resolutions=[61, 121], hw_ratio=2, in_channels=4, latent_resolution=7,
+                             is_periodic=False, cond_channels=1, cond_emb_channels=64, cond_encoder=True,
+                             attn_resolutions=[15, 30], decoder_attn_heads=8, decoder_attn_dim=64,
+                             prop_n_block=4, dilation=2),
+    # the same at a size the CPU suite runs in seconds
+    "cond_ae_mini": dict(family="twophase", latent_dim=8, Ly=29, Lx=57, resolutions=[29, 57], hw_ratio=2,
+                         in_channels=3, latent_resolution=7, is_periodic=False, cond_channels=1, cond_emb_channels=16,
+                         cond_encoder=True, encoder_channels=[32, 32, 64, 64], fourier_resolutions=[],
+                         encoder_res_blocks=1, use_attn_enc=False, use_fa=True, decoder_channels=[64, 32, 32],
+                         attn_resolutions=[14], decoder_res_blocks=1, final_smoothing=False,
+                         decoder_attn_heads=2, decoder_attn_dim=32, disable_coarse_attn=False, noise_level=0.0,
+                         prop_n_block=2, prop_n_embd=64, dilation=2),
     # configs/twophase_stage2_prop.yml (unconditional two-phase)
     "twophase": dict(_COMMON, family="twophase", latent_dim=64, Ly=61, Lx=121,
                      resolutions=[61, 121], hw_ratio=2, in_channels=4, latent_resolution=7,

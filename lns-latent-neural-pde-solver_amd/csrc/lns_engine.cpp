@@ -744,24 +744,66 @@ struct Planner {
         cond_pool_used += bytes;
         return off;
     }
-    void emit_cond_base() {
-        const lns_config& c = e->cfg;
-        const int E = c.cond_emb_dim, half = E / 2;
+    // ce = W2 act(W0 fourier_embedding(param, E) + b0) + b2 for the MLP `mlp`.{i0,i2} (in-major vec packs)
+    void emit_cond_base(const std::string& mlp, const char* i0, const char* i2, int E, int Hd, int act, size_t ce_off) {
+        const int half = E / 2;
         std::vector<float> fr(half);
         for (int i = 0; i < half; ++i) fr[i] = (float)std::exp(-std::log(10000.0) * (double)((float)i) / (double)half);
-        const std::string p = c.prop_prefix;
         Op op;
-        op.type = OP_CONDBASE; op.name = p + "cond_emb_proj"; op.cls = CLS_COND;
-        op.cb.param = as_ptr<const float>(tag(SP_EXT0 + EX_PARAM, 0)); op.cb.B = B; op.cb.E = E;
+        op.type = OP_CONDBASE; op.name = mlp; op.cls = CLS_COND;
+        memset(&op.cb, 0, sizeof op.cb);
+        op.cb.param = as_ptr<const float>(tag(SP_EXT0 + EX_PARAM, 0)); op.cb.B = B; op.cb.E = E; op.cb.Hd = Hd; op.cb.act = act;
         op.cb.freqs = as_ptr<const float>(const_floats(fr));
-        op.cb.w0_t = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.0.weight")));
-        op.cb.b0 = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.0.bias")));
-        op.cb.w2_t = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.2.weight")));
-        op.cb.b2 = as_ptr<const float>(vecp(vec_id(p + "cond_emb_proj.2.bias")));
-        cond_ce_off = cond_take((size_t)B * E * 4);
+        op.cb.w0_t = as_ptr<const float>(vecp(vec_id(mlp + "." + i0 + ".weight")));
+        op.cb.b0 = as_ptr<const float>(vecp(vec_id(mlp + "." + i0 + ".bias")));
+        op.cb.w2_t = as_ptr<const float>(vecp(vec_id(mlp + "." + i2 + ".weight")));
+        op.cb.b2 = as_ptr<const float>(vecp(vec_id(mlp + "." + i2 + ".bias")));
+        cond_ce_off = ce_off;
         cond_ce = tag(SP_WS, cond_ce_off); cond_ce_live = true;
         op.cb.ce = as_ptr<float>(cond_ce);
         plan->ops.push_back(op);
+    }
+    // conditional propagator, step-invariant part: cond_emb_proj(fourier_embedding(param))
+    // train_stage2_twophase_conditional.py:116, modules/cond_utils.py:19-38
+    void emit_cond_base() {
+        const lns_config& c = e->cfg;
+        const int E = c.cond_emb_dim;
+        emit_cond_base(std::string(c.prop_prefix) + "cond_emb_proj", "0", "2", E, E, ACT_GELU, cond_take((size_t)B * E * 4));
+    }
+
+    // CondResidualBlock (norm=True, n_groups=1, GELU, use_scale_shift_norm=False): modules/cond_utils.py:112-128
+    //   h = conv1(gelu(GN1(x))) + Linear(cond_emb)[:, :, None, None];  out = conv2(gelu(GN1(h))) + shortcut(x)
+    TRef lower_condres(const Layer& l, TRef x, bool raw_out) {
+        if (x.pending()) throw std::runtime_error("CondResidualBlock input must be materialised: " + l.name);
+        if (!cond_ce_live) throw std::runtime_error("CondResidualBlock without a conditioning embedding: " + l.name);
+        const int E = l.cr_E;
+        // emb_out = cond_emb(emb): [B, cout], weights in the reference's [out][in] layout
+        const size_t emb_off = arena.alloc((size_t)B * l.cout * 4);
+        {
+            Op op;
+            op.type = OP_VECLIN; op.name = l.name + ".cond_emb"; op.cls = CLS_COND;
+            op.vl.in = as_ptr<const float>(cond_ce); op.vl.w = as_ptr<const float>(vecp(l.cr_lin_w));
+            op.vl.bias = as_ptr<const float>(vecp(l.cr_lin_b)); op.vl.out = as_ptr<float>(tag(SP_WS, emb_off));
+            op.vl.B = B; op.vl.In = E; op.vl.Out = l.cout; op.vl.ldi = E; op.vl.ldo = 1;
+            plan->ops.push_back(op);
+        }
+        TRef skip = x;
+        bool skip_owned = false;
+        if (l.chup >= 0) { skip = conv_same1(x, l.chup, ACT_NONE, nullptr, nullptr, l.name + ".shortcut", -1, false); skip_owned = true; }
+        TRef xin = x; xin.owned = false;
+        emit_gn(xin, 1, 1e-5f, l.g1, l.b1, 0, l.name + ".norm1");
+        TRef a1 = emit_apply(xin, ACT_GELU, l.name + ".act1");          // (the conv prologue knows Swish only)
+        free_t(xin);
+        TRef h1 = conv_same3(a1, l.conv1, 1, l.mode_y, l.mode_x, ACT_NONE, nullptr, tag(SP_WS, emb_off), l.name + ".conv1", false);
+        free_t(a1);
+        arena.release(emb_off);
+        emit_gn(h1, 1, 1e-5f, l.g2, l.b2, 0, l.name + ".norm2");
+        TRef a2 = emit_apply(h1, ACT_GELU, l.name + ".act2");
+        free_t(h1);
+        TRef out = conv_same3(a2, l.conv2, 1, l.mode_y, l.mode_x, ACT_NONE, &skip, 0, l.name + ".conv2", raw_out);
+        free_t(a2);
+        if (skip_owned) free_t(skip);
+        return out;
     }
 
     // conditional DilatedResidualBlock: train_stage2_twophase_conditional.py:25-75
@@ -836,7 +878,7 @@ struct Planner {
             op.type = OP_FCOMBINE; op.name = l.name + ".combine"; op.cls = CLS_MISC;
             op.fc.a = as_ptr<const float>(x1.ptr); op.fc.b = as_ptr<const float>(x2.ptr); op.fc.e = nullptr;
             op.fc.skip = as_ptr<const float>(x.ptr); op.fc.skip_bs = x.bs; op.fc.y = as_ptr<float>(out.ptr);
-            op.fc.y_bs = out.bs; op.fc.B = B; op.fc.C = C; op.fc.HW = H * W;
+            op.fc.y_bs = out.bs; op.fc.B = B; op.fc.C = C; op.fc.HW = H * W; op.fc.act = ACT_GELU;
             out.amax = 0; out.amax_const = 0.0f; out.gn_bound = 0.0f; op.fc.amax_out = nullptr;
             if (raw_out && !out_forced) { out.amax = new_amax(l.name + ".combine"); op.fc.amax_out = as_ptr<unsigned>(out.amax); }
             plan->ops.push_back(op);
@@ -851,7 +893,7 @@ struct Planner {
         if (j >= L.size()) return false;                       // the program's output
         switch (L[j].type) {
             case LT_CONV: case LT_UP2: case LT_RESIZE: case LT_FOURIER: return true;
-            case LT_RES: return L[j].chup >= 0;
+            case LT_RES: case LT_CONDRES: return L[j].chup >= 0;
             default: return false;                             // GroupNorm / LayerNorm first (GN, SA, FA, propagator blocks), Swish
         }
     }
@@ -904,6 +946,7 @@ struct Planner {
                     if (!cond_ce_live) emit_cond_base();
                     nxt = lower_condblock(l, cur, raw_next); free_t(cur); trace(l.name, nxt); break;
                 case LT_FOURIER: nxt = lower_fourier(l, cur, nullptr, raw_next); free_t(cur); trace(l.name, nxt); break;
+                case LT_CONDRES: nxt = lower_condres(l, cur, raw_next); free_t(cur); trace(l.name, nxt); break;
                 default: throw std::runtime_error("layer type not supported by this build: " + l.name);
             }
             if (last && l.type != LT_CONV) throw std::runtime_error("program must end in a convolution");
@@ -1055,6 +1098,9 @@ static int get_plan(lns_engine* e, PlanKind kind, int B, int H, int W, Plan** ou
         if (kind == PK_PROP) pl.init_cond_pool();
         if (kind == PK_ENC) {
             if (e->enc.empty()) throw std::runtime_error("engine has no autoencoder");
+            if (c.cond_encoder)   // CondEncoder.forward: cond_emb = embed(fourier_embedding(param, E))  (autoencoder2d_nonsquared.py:128)
+                pl.emit_cond_base(std::string(c.ae_prefix) + "encoder.embed", "0", "2", c.cond_emb_channels, c.encoder_channels[0],
+                                  ACT_SWISH, pl.arena.alloc((size_t)B * c.cond_emb_channels * 4));
             pl.lower_sequence(e->enc, ext_tensor(EX_IN, c.in_channels, c.Ly, c.Lx),
                               ext_tensor(EX_OUT, e->lat_C, e->lat_H, e->lat_W));
         } else if (kind == PK_DEC) {
@@ -1219,6 +1265,12 @@ struct Runner {
                     FourierCombineArgs a = op.fc;
                     fix(a.a, B); fix(a.b, B); fix(a.e, B); fix(a.skip, B); fix(a.y, B); fix(a.amax_out, B); fixbs(a.skip_bs, B); fixbs(a.y_bs, B);
                     rc = launch_fourier_combine(a, stream);
+                    break;
+                }
+                case OP_VECLIN: {
+                    VecLinearArgs a = op.vl;
+                    fix(a.in, B); fix(a.w, B); fix(a.bias, B); fix(a.out, B);
+                    rc = launch_vec_linear(a, stream);
                     break;
                 }
                 case OP_TRACE: {
@@ -1484,7 +1536,20 @@ static int check_ws(lns_engine* e, const WsLayout& L, void* ws, size_t bytes) {
     return LNS_OK;
 }
 
+static int encode_impl(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream);
+
 int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
+    if (e && e->cfg.cond_encoder) { e->err = "this autoencoder's encoder is conditional: use lns_encode_cond(x, param)"; return LNS_EINVAL; }
+    return encode_impl(e, x, nullptr, B, z, ws, ws_bytes, stream);
+}
+
+int lns_encode_cond(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
+    if (e && !e->cfg.cond_encoder) { e->err = "lns_encode_cond needs cfg.cond_encoder"; return LNS_EINVAL; }
+    if (!param) { if (e) e->err = "conditional encoder needs param"; return LNS_EINVAL; }
+    return encode_impl(e, x, param, B, z, ws, ws_bytes, stream);
+}
+
+static int encode_impl(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
     if (!e || !x || !z || B <= 0) return LNS_EINVAL;
     if (int brc = check_batch(e, B)) return brc;
     DeviceGuard dg(e);
@@ -1496,6 +1561,7 @@ int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t 
     ExtT ext[EX_COUNT];
     ext[EX_IN] = {x, (long)c.in_channels * c.Ly * c.Lx};
     ext[EX_OUT] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
+    ext[EX_PARAM] = {param, 1};
     Runner r(e, static_cast<hipStream_t>(stream));
     e->ran.clear();
     if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
@@ -1658,7 +1724,7 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
     if (!e || !x || !out || B <= 0 || T <= 0) return LNS_EINVAL;
     if (int brc = check_batch(e, B)) return brc;
     if (e->enc.empty() || e->prop.empty()) { e->err = "rollout needs autoencoder and propagator"; return LNS_ESTATE; }
-    if (e->cfg.prop_kind == LNS_PROP_CONDITIONAL && !param) { e->err = "conditional propagator needs param"; return LNS_EINVAL; }
+    if ((e->cfg.prop_kind == LNS_PROP_CONDITIONAL || e->cfg.cond_encoder) && !param) { e->err = "conditional model needs param"; return LNS_EINVAL; }
     DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
@@ -2013,19 +2079,24 @@ int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, 
     return LNS_OK;
 }
 
-int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int m2, const float* w1_host,
+int lns_op_fourier_block(const float* x, int B, int Cin, int Cout, int H, int W, int m1, int m2, const float* w1_host,
                          const float* w2_host, const float* conv_w_host, const float* conv_b_host, const float* cond,
                          const float* freq_w_host, const float* freq_b_host, const float* lin_w_host,
-                         const float* lin_b_host, float* y, void* stream) {
-    if (!x || !y || !w1_host || !w2_host || !conv_w_host || B <= 0 || 2 * m1 > H || m2 > W / 2 + 1) return LNS_EINVAL;
+                         const float* lin_b_host, int activation, int residual, float* y, void* stream) {
+    if (!x || !y || !w1_host || !w2_host || !conv_w_host || B <= 0 || Cin <= 0 || Cout <= 0 || 2 * m1 > H || m2 > W / 2 + 1)
+        return LNS_EINVAL;
     if (cond && (!freq_w_host || !freq_b_host || !lin_w_host || !lin_b_host)) return LNS_EINVAL;
+    if (residual && Cin != Cout) return LNS_EINVAL;                // x_skip + out needs matching shapes (basics.py:581-582)
+    if (activation < ACT_SWISH || activation > ACT_SIGMOID) return LNS_EINVAL;
     OPCHK(init_kernels());
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t nw = (size_t)C * C * m1 * m2 * 2, nf = (size_t)4 * m1 * m2;
-    const size_t t1n = (size_t)B * C * H * m2 * 2, xfn = (size_t)B * C * 2 * m1 * m2 * 2, act = (size_t)B * C * H * W;
+    const size_t nw = (size_t)Cin * Cout * m1 * m2 * 2, nf = (size_t)4 * m1 * m2;
+    const size_t t1n = (size_t)B * std::max(Cin, Cout) * H * m2 * 2, xfi = (size_t)B * Cin * 2 * m1 * m2 * 2,
+                 xfo = (size_t)B * Cout * 2 * m1 * m2 * 2, act = (size_t)B * Cout * H * W;
     // one scratch allocation: [w1 | w2 | freq_w | freq_b | lin_w | lin_b | emb | e | t1 | xf | of | x1 | x2]
-    std::vector<size_t> sz = {nw, nw, (size_t)C * nf, nf, (size_t)C * C, (size_t)C, (size_t)B * nf, (size_t)B * C,
-                              t1n, xfn, xfn, act, act};
+    // (conditional block: the conditioning vector has in_planes entries, fourier_cond.py:102-104)
+    std::vector<size_t> sz = {nw, nw, (size_t)Cin * nf, nf, (size_t)Cout * Cin, (size_t)Cout, (size_t)B * nf, (size_t)B * Cout,
+                              t1n, xfi, xfo, act, act};
     std::vector<size_t> off(sz.size());
     size_t tot = 0;
     for (size_t i = 0; i < sz.size(); ++i) { off[i] = tot; tot += (sz[i] + 63) / 64 * 64; }
@@ -2034,28 +2105,28 @@ int lns_op_fourier_block(const float* x, int B, int C, int H, int W, int m1, int
     OPCHK(hipMemcpy(d + off[0], w1_host, nw * 4, hipMemcpyHostToDevice));
     OPCHK(hipMemcpy(d + off[1], w2_host, nw * 4, hipMemcpyHostToDevice));
     if (cond) {
-        OPCHK(hipMemcpy(d + off[2], freq_w_host, (size_t)C * nf * 4, hipMemcpyHostToDevice));
+        OPCHK(hipMemcpy(d + off[2], freq_w_host, (size_t)Cin * nf * 4, hipMemcpyHostToDevice));
         OPCHK(hipMemcpy(d + off[3], freq_b_host, nf * 4, hipMemcpyHostToDevice));
-        OPCHK(hipMemcpy(d + off[4], lin_w_host, (size_t)C * C * 4, hipMemcpyHostToDevice));
-        OPCHK(hipMemcpy(d + off[5], lin_b_host, (size_t)C * 4, hipMemcpyHostToDevice));
-        // FreqLinear: h = cond @ weights[C, 4 m1 m2] + bias      (fourier_cond.py:25-29)
-        VecLinearArgs fl = {cond, d + off[2], d + off[3], d + off[6], B, C, (int)nf, 1, (int)nf};
+        OPCHK(hipMemcpy(d + off[4], lin_w_host, (size_t)Cout * Cin * 4, hipMemcpyHostToDevice));
+        OPCHK(hipMemcpy(d + off[5], lin_b_host, (size_t)Cout * 4, hipMemcpyHostToDevice));
+        // FreqLinear: h = cond @ weights[Cin, 4 m1 m2] + bias      (fourier_cond.py:25-29)
+        VecLinearArgs fl = {cond, d + off[2], d + off[3], d + off[6], B, Cin, (int)nf, 1, (int)nf};
         OPCHK(launch_vec_linear(fl, s));
         // emb_out = Linear(cond): weight [out, in]                (fourier_cond.py:104,111)
-        VecLinearArgs ll = {cond, d + off[4], d + off[5], d + off[7], B, C, C, C, 1};
+        VecLinearArgs ll = {cond, d + off[4], d + off[5], d + off[7], B, Cin, Cout, Cin, 1};
         OPCHK(launch_vec_linear(ll, s));
     }
     SpectralArgs sp;
     memset(&sp, 0, sizeof sp);
-    sp.x = x; sp.x_bs = (long)C * H * W; sp.B = B; sp.Cin = C; sp.Cout = C; sp.H = H; sp.W = W; sp.m1 = m1; sp.m2 = m2;
+    sp.x = x; sp.x_bs = (long)Cin * H * W; sp.B = B; sp.Cin = Cin; sp.Cout = Cout; sp.H = H; sp.W = W; sp.m1 = m1; sp.m2 = m2;
     sp.w1 = d + off[0]; sp.w2 = d + off[1]; sp.emb = cond ? d + off[6] : nullptr;
     sp.t1 = d + off[8]; sp.xf = d + off[9]; sp.of = d + off[10]; sp.y = d + off[11];
     OPCHK(launch_spectral(sp, s));
-    int rc = lns_op_conv2d(x, B, C, H, W, H, W, conv_w_host, conv_b_host, C, 1, 1, 1, 0, 0, 0, 0, 0, 0, nullptr, 0, 0,
+    int rc = lns_op_conv2d(x, B, Cin, H, W, H, W, conv_w_host, conv_b_host, Cout, 1, 1, 1, 0, 0, 0, 0, 0, 0, nullptr, 0, 0,
                            nullptr, nullptr, d + off[12], -1, stream, nullptr);
     if (rc) { (void)hipFree(d); return rc; }
-    FourierCombineArgs fc = {d + off[11], d + off[12], cond ? d + off[7] : nullptr, x, (long)C * H * W, y,
-                             (long)C * H * W, B, C, H * W, nullptr};
+    FourierCombineArgs fc = {d + off[11], d + off[12], cond ? d + off[7] : nullptr, residual ? x : nullptr, (long)Cin * H * W, y,
+                             (long)Cout * H * W, B, Cout, H * W, nullptr, activation};
     OPCHK(launch_fourier_combine(fc, s));
     OPCHK(hipStreamSynchronize(s));
     (void)hipFree(d);

@@ -36,7 +36,7 @@ enum VecXform { VX_NONE = 0, VX_TRANSPOSE2D = 1, VX_PE_T = 2 };
 struct VecPack { std::string key; int xform = VX_NONE; size_t off = 0; size_t count = 0; };
 
 // ---- layer IR (mirrors the reference nn.Sequential entries) ------------------
-enum LType { LT_CONV, LT_SWISH, LT_GN, LT_RES, LT_UP2, LT_RESIZE, LT_SA, LT_FA, LT_FOURIER, LT_PROPBLOCK, LT_CONDBLOCK };
+enum LType { LT_CONV, LT_SWISH, LT_GN, LT_RES, LT_UP2, LT_RESIZE, LT_SA, LT_FA, LT_FOURIER, LT_PROPBLOCK, LT_CONDBLOCK, LT_CONDRES };
 
 struct Layer {
     LType type = LT_CONV;
@@ -62,6 +62,8 @@ struct Layer {
     int p_g1 = -1, p_b1 = -1, p_c1 = -1, p_c3 = -1, p_c5 = -1, p_g2 = -1, p_b2 = -1, p_f1 = -1, p_f3 = -1;
     // conditional block extras
     int c_g = -1, c_b = -1, c_conv = -1, blk_index = 0;
+    // CondResidualBlock (cond_utils.py:58-128): cr_lin_w / cr_lin_b = cond_emb Linear (vec ids), E = its input width
+    int cr_lin_w = -1, cr_lin_b = -1, cr_E = 0;
     // fourier block
     int f_conv = -1, f_w1 = -1, f_w2 = -1, m1 = 0, m2 = 0, f_cond_w = -1, f_cond_b = -1, f_lin = -1;
 };
@@ -71,7 +73,7 @@ enum Space { SP_NULL = 0, SP_WS = 1, SP_WT = 2, SP_CT = 3, SP_EXT0 = 4 };   // e
 enum ExtSlot { EX_IN = 0, EX_OUT = 1, EX_PARAM = 2, EX_COUNT = 3 };
 
 enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FARED2, OP_FALRK, OP_FALRK2, OP_FASAND, OP_CONDBASE, OP_CONDBLK,
-              OP_APPLY, OP_SPECTRAL, OP_FCOMBINE, OP_TRACE };
+              OP_APPLY, OP_SPECTRAL, OP_FCOMBINE, OP_VECLIN, OP_TRACE };
 
 struct Op {
     OpType type;
@@ -94,6 +96,7 @@ struct Op {
     ApplyArgs ap;
     SpectralArgs sp;
     FourierCombineArgs fc;
+    VecLinearArgs vl;
     // trace
     uint64_t t_ptr = 0; long t_bs = 0; int tC = 0, tH = 0, tW = 0;
 };

@@ -6,7 +6,7 @@
 
 namespace lns {
 
-enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_GELU = 2 };
+enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
 
 // ---------------------------------------------------------------------------
 // fused implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32)
@@ -183,11 +183,13 @@ hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s);
 size_t fa_sandwich_lds_bytes(int H, int W);
 
 // conditional propagator: per-sample embedding MLPs (tiny; step-invariant) ------
-struct CondBaseArgs {            // ce = W2 gelu(W0 fourier_embedding(param) + b0) + b2
+struct CondBaseArgs {            // ce = W2 act(W0 fourier_embedding(param) + b0) + b2
     const float* param; int B, E;
     const float* freqs;          // [E/2]
-    const float* w0_t; const float* b0; const float* w2_t; const float* b2;   // in-major [E][E]
+    const float* w0_t; const float* b0; const float* w2_t; const float* b2;   // in-major [E][Hd], [Hd][E]
     float* ce;                   // [B][E]
+    int Hd;                      // hidden width (0: E)
+    int act;                     // ACT_GELU (conditional propagator) / ACT_SWISH (CondEncoder.embed)
 };
 hipError_t launch_cond_base(const CondBaseArgs& a, hipStream_t s);
 struct CondBlockArgs {           // emb = Wce ce + bce ; mul = 1 + conv1(gelu(conv1(GN1(emb))))
@@ -218,8 +220,8 @@ struct SpectralArgs {
 };
 hipError_t launch_spectral(const SpectralArgs& a, hipStream_t s);
 
-// y = skip + gelu(a + b + e[b,c])
-struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; long skip_bs; float* y; long y_bs; int B, C, HW; unsigned* amax_out; };
+// y = [skip +] act(a + b + e[b,c])     (skip null: residual=False; act 0: GELU)
+struct FourierCombineArgs { const float* a; const float* b; const float* e; const float* skip; long skip_bs; float* y; long y_bs; int B, C, HW; unsigned* amax_out; int act; };
 hipError_t launch_fourier_combine(const FourierCombineArgs& a, hipStream_t s);
 
 // out[b,o] = bias[o] + sum_i in[b,i] * w[i*ldo + o*ldi]   (tiny dense layer on per-sample vectors)

@@ -50,6 +50,9 @@ __device__ __forceinline__ float gelu_erfc(float v) {
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == ACT_SWISH) return v / (1.0f + expf(-v));
     if (act == ACT_GELU) return gelu_erfc(v);
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
 }
 
@@ -3311,20 +3314,21 @@ __global__ __launch_bounds__(128) void cond_base_kernel(CondBaseArgs a) {
         v0[i] = val;
     }
     __syncthreads();
-    for (int o = tid; o < E; o += 128) {
+    const int Hd = a.Hd > 0 ? a.Hd : E;
+    for (int o = tid; o < Hd; o += 128) {
         float acc = a.b0[o];
-        for (int i = 0; i < E; ++i) acc += a.w0_t[i * E + o] * v0[i];
-        v1[o] = act_apply(acc, ACT_GELU);
+        for (int i = 0; i < E; ++i) acc += a.w0_t[i * Hd + o] * v0[i];
+        v1[o] = act_apply(acc, a.act ? a.act : ACT_GELU);
     }
     __syncthreads();
     for (int o = tid; o < E; o += 128) {
         float acc = a.b2[o];
-        for (int i = 0; i < E; ++i) acc += a.w2_t[i * E + o] * v1[i];
+        for (int i = 0; i < Hd; ++i) acc += a.w2_t[i * E + o] * v1[i];
         a.ce[(long)b * E + o] = acc;
     }
 }
 hipError_t launch_cond_base(const CondBaseArgs& a, hipStream_t s) {
-    if (a.E > 256) return hipErrorInvalidValue;
+    if (a.E > 256 || a.Hd > 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL(cond_base_kernel, dim3(a.B), dim3(128), 0, s, a);
     return hipGetLastError();
 }
@@ -3518,11 +3522,12 @@ __global__ __launch_bounds__(256) void fourier_combine_kernel(FourierCombineArgs
     const int c = blockIdx.x, b = blockIdx.y;
     const long base = ((long)b * a.C + c) * a.HW;
     const float e = a.e ? a.e[(long)b * a.C + c] : 0.0f;
-    const float* sk = a.skip + (long)b * a.skip_bs + (long)c * a.HW;
+    const float* sk = a.skip ? a.skip + (long)b * a.skip_bs + (long)c * a.HW : nullptr;
     float* ys = a.y + (long)b * a.y_bs + (long)c * a.HW;
+    const int act = a.act ? a.act : ACT_GELU;
     unsigned am = 0u;
     for (int i = threadIdx.x; i < a.HW; i += 256) {
-        const float v = sk[i] + act_apply(a.a[base + i] + a.b[base + i] + e, ACT_GELU);
+        const float v = (sk ? sk[i] : 0.0f) + act_apply(a.a[base + i] + a.b[base + i] + e, act);
         ys[i] = v;
         am = max(am, abs_bits(v));
     }

@@ -275,6 +275,63 @@ static void build_encoder(Builder& b, const lns_config& c, std::vector<Layer>& L
     L.push_back(conv_layer(name(idx), b.conv(name(idx), cl, c.latent_dim, 1), 1, 1, 1, 0, 0, 0, 0, 0, 0));
 }
 
+// CondResidualBlock(in, out, cond_channels, norm=True, n_groups=1, GELU): modules/cond_utils.py:58-128
+static Layer cond_res_layer(Builder& b, const std::string& p, int cin, int cout, int E, int my, int mx) {
+    Layer l;
+    l.type = LT_CONDRES; l.name = p; l.cin = cin; l.cout = cout; l.mode_y = my; l.mode_x = mx; l.cr_E = E;
+    l.conv1 = b.conv(p + ".conv1", cin, cout, 3);
+    l.conv2 = b.conv(p + ".conv2", cout, cout, 3);
+    if (cin != cout) l.chup = b.conv(p + ".shortcut", cin, cout, 1);
+    l.g1 = b.vec_param(p + ".norm1.weight", {cin});
+    l.b1 = b.vec_param(p + ".norm1.bias", {cin});
+    l.g2 = b.vec_param(p + ".norm2.weight", {cout});
+    l.b2 = b.vec_param(p + ".norm2.bias", {cout});
+    l.cr_lin_w = b.vec_param(p + ".cond_emb.weight", {cout, E});
+    l.cr_lin_b = b.vec_param(p + ".cond_emb.bias", {cout});
+    return l;
+}
+
+// CondEncoder: modules/autoencoder2d_nonsquared.py:71-145
+static void build_cond_encoder(Builder& b, const lns_config& c, std::vector<Layer>& L) {
+    const std::string p = std::string(c.ae_prefix) + "encoder.";
+    const int my = c.ae_pad_y, mx = c.ae_pad_x;
+    const int n = c.n_encoder_channels, E = c.cond_emb_channels;
+    const int32_t* ch = c.encoder_channels;
+    if (c.ae_kind != LNS_AE_NONSQUARED) throw std::runtime_error("cond_encoder needs the non-squared autoencoder");
+    if (E <= 0 || E > 256 || ch[0] > 256) throw std::runtime_error("cond_emb_channels / encoder_channels[0] out of range");
+    if (n - 2 != (int)std::log2((double)(c.res_h / c.latent_resolution)))
+        throw std::runtime_error("len(encoder_channels)-2 must equal log2(resolution//latent_resolution)");
+    // to_in: 1x1 -> Swish -> 3x3
+    L.push_back(conv_layer(p + "to_in.0", b.conv(p + "to_in.0", c.in_channels, ch[0], 1), 1, 1, 1, 0, 0, 0, 0, 0, 0));
+    L.push_back(swish_layer(p + "to_in.1"));
+    L.push_back(same_conv(b, p + "to_in.2", ch[0], ch[0], 3, my, mx));
+    // embed: Linear(E, ch0) -> Swish -> Linear(ch0, E) on fourier_embedding(param, E)   (:104-106, :128)
+    b.vec_param(p + "embed.0.weight", {ch[0], E}, VX_TRANSPOSE2D);
+    b.vec_param(p + "embed.0.bias", {ch[0]});
+    b.vec_param(p + "embed.2.weight", {E, ch[0]}, VX_TRANSPOSE2D);
+    b.vec_param(p + "embed.2.bias", {E});
+    for (int i = 0; i < n - 1; ++i) {
+        int cin = ch[i];
+        const int cout = ch[i + 1];
+        const std::string q = p + "layers." + std::to_string(i);
+        for (int j = 0; j < c.encoder_res_blocks; ++j) {
+            L.push_back(cond_res_layer(b, q + ".0." + std::to_string(j), cin, cout, E, my, mx));
+            cin = cout;
+        }
+        if (i != n - 2) {
+            const std::string dn = q + ".1.conv_layer";
+            const int pk = b.conv(dn, cout, cout, 3);
+            if (my == LNS_PAD_CIRCULAR) L.push_back(conv_layer(dn, pk, 3, 2, 1, 1, 1, 1, 1, LNS_PAD_CIRCULAR, LNS_PAD_CIRCULAR));
+            else L.push_back(conv_layer(dn, pk, 3, 2, 1, 0, 1, 0, 1, LNS_PAD_ZEROS, LNS_PAD_ZEROS));
+        }
+    }
+    const int cl = ch[n - 1];
+    L.push_back(cond_res_layer(b, p + "to_out_conv", cl, cl, E, my, mx));
+    L.push_back(gn32_layer(b, p + "to_out.0", cl));
+    L.push_back(swish_layer(p + "to_out.1"));
+    L.push_back(conv_layer(p + "to_out.2", b.conv(p + "to_out.2", cl, c.latent_dim, 1), 1, 1, 1, 0, 0, 0, 0, 0, 0));
+}
+
 // ---------------------------------------------------------------------------
 // Decoders: modules/autoencoder2d.py:75-156, autoencoder2d_nonsquared.py:148-247,
 //           autoencoder2d_half_periodic.py:147-230
@@ -419,7 +476,8 @@ void build_model(lns_engine* e) {
         if (c.n_encoder_channels < 2 || c.n_encoder_channels > LNS_MAX_STAGES || c.n_decoder_channels < 1 ||
             c.n_decoder_channels > LNS_MAX_STAGES)
             throw std::runtime_error("bad channel list length");
-        build_encoder(b, c, e->enc);
+        if (c.cond_encoder) build_cond_encoder(b, c, e->enc);
+        else build_encoder(b, c, e->enc);
         build_decoder(b, c, e->dec);
         const std::string q = std::string(c.ae_prefix) + "quant_conv";
         e->enc.push_back(conv_layer(q, b.conv(q, c.latent_dim, c.latent_dim, 1), 1, 1, 1, 0, 0, 0, 0, 0, 0));

@@ -39,7 +39,8 @@ def _init_value(key, shape, sibling_weight_shape):
     leaf = key.rsplit(".", 1)[-1]
     t = torch.empty(shape, dtype=torch.float32)
     sa = any(s in key for s in (".to_q.", ".to_k.", ".to_v.", ".proj_out."))
-    zero = (".cond_conv1.2." in key) or (".cond_conv2.3." in key)
+    zero = (".cond_conv1.2." in key) or (".cond_conv2.3." in key) or \
+        (key.startswith("encoder.") and ".conv2." in key and (".layers." in key or ".to_out_conv." in key))   # zero_module (cond_utils.py:96-97)
     if leaf == "inv_freq":
         dim = 2 * shape[0]
         return 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
@@ -157,6 +158,31 @@ class SimpleAutoencoderNonSquared(SimpleAutoencoder):
 
 class SimpleAutoencoderHalfPeriodic(SimpleAutoencoder):
     _ae_kind = LNS_AE_HALF_PERIODIC
+
+
+class ConditionalSimpleAutoencoder(SimpleAutoencoder):
+    """modules/autoencoder2d_nonsquared.py:279-305: `CondEncoder` (:71-145, `CondResidualBlock`s conditioned on
+    embed(fourier_embedding(param)), modules/cond_utils.py:58-128) + the plain non-squared Decoder.
+    encode(x, param) / decode(z) / forward(x, param); state_dict keys as the reference's
+    (`encoder.to_in.*`, `encoder.embed.*`, `encoder.layers.i.0.j.{conv1,conv2,shortcut,norm1,norm2,cond_emb}.*`,
+    `encoder.layers.i.1.conv_layer.*`, `encoder.to_out_conv.*`, `encoder.to_out.*`, `decoder.model.*`, ...)."""
+    _ae_kind = LNS_AE_NONSQUARED
+
+    def __init__(self, args):
+        if not getattr(args, "cond_encoder", False):
+            args = types.SimpleNamespace(**vars(args))
+            args.cond_encoder = True
+        super().__init__(args)
+
+    @torch.no_grad()
+    def encode(self, x, param):
+        return self._engine(x).encode(x, param)
+
+    def forward(self, x, param):
+        return self.decode(self.encode(x, param))
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path), strict=True)
 
 
 # ---------------------------------------------------------------------------

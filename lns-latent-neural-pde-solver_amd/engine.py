@@ -95,6 +95,12 @@ def make_config(args, ae_kind=None, prop_kind=None, ae_prefix="", prop_prefix=""
                             fam, (LNS_PAD_ZEROS, LNS_PAD_ZEROS))
         c.prop_pad_y, c.prop_pad_x = prop_pad
         c.cond_emb_dim = int(getattr(args, "cond_emb_dim", args.latent_dim))
+    if getattr(args, "cond_encoder", False):
+        # ConditionalSimpleAutoencoder (modules/autoencoder2d_nonsquared.py:279-305): CondEncoder + plain Decoder
+        if ae_kind != LNS_AE_NONSQUARED:
+            raise ValueError("cond_encoder is defined for the non-squared autoencoder only")
+        c.cond_encoder = 1
+        c.cond_emb_channels = int(args.cond_emb_channels)
     c.ae_prefix = ae_prefix.encode()
     c.prop_prefix = prop_prefix.encode()
     return c
@@ -213,13 +219,20 @@ class Engine:
             raise LnsError("fp32 tensors expected, got %s" % t.dtype)
         return t.contiguous()
 
-    def encode(self, x):
+    def encode(self, x, param=None):
         import torch
         x = self._dev(x)
         B = x.shape[0]
         C, H, W = self.latent_shape()
         z = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         ws = self._workspace(B, x.device)
+        if self.cfg.cond_encoder:
+            if param is None:
+                raise LnsError("this autoencoder's encoder is conditional: encode(x, param)")
+            p = self._param(param, x)
+            self._check(self._L.lns_encode_cond(self._h, x.data_ptr(), p.data_ptr(), B, z.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), self._stream(x)), "lns_encode_cond")
+            return z
         self._check(self._L.lns_encode(self._h, x.data_ptr(), B, z.data_ptr(), ws.data_ptr(), ws.numel(),
                                        self._stream(x)), "lns_encode")
         return z

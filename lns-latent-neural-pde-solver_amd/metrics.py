@@ -77,16 +77,45 @@ def _launch_metric(L, per_channel, y_hat, y, B, T, C, H, W, mean, std, eps, zero
     return rc
 
 
+def sw_norm(u_mean, u_std, v_mean, v_std, pres_mean, pres_std):
+    """Keyword arguments for encode_dataset restating Stage2_SW.normalize (dataset/Stage2_SW.py:74-78): channels
+    (u, v, pres), each by its own statistics, no epsilon."""
+    return dict(mean=[u_mean, v_mean, pres_mean], std=[u_std, v_std, pres_std], eps=0.0)
+
+
+def twophase_norm(vel_mean, vel_std, prs_mean, prs_std):
+    """Keyword arguments for encode_dataset restating TwoPhaseFlow.normalize_data + the channel layout of its
+    encode_dataset (dataset/twophase_flow_stage2.py:304-313, :325-326): (u, v) by the velocity statistics, pressure by its
+    own, the VOF channel as is; chunks of 32 frames (:329-334)."""
+    return dict(mean=[vel_mean, vel_mean, prs_mean, 0.0], std=[vel_std, vel_std, prs_std, 1.0], eps=0.0, chunk=32)
+
+
 @torch.no_grad()
-def encode_dataset(autoencoder, frames, chunk=32, mean=0.0, std=1.0, out_device="cpu"):
+def encode_dataset(autoencoder, frames, chunk=32, mean=0.0, std=1.0, eps=1e-8, out_device="cpu", param=None):
     """Pre-encodes a whole trajectory set for stage-2 training: frames [N,C,H,W] (raw, un-normalised; torch tensor or
-    numpy array) -> latents [N, latent_dim, h, w], `chunk` frames per encoder call as the reference's datasets do,
-    with the dataset normalisation (u - mean) / (std + 1e-8) applied first."""
+    numpy array) -> latents [N, latent_dim, h, w], `chunk` frames per encoder call, with the dataset normalisation
+    (u - mean) / (std + eps) applied first on the device.  mean / std: scalars (NS2d,
+    dataset/ns2d_fno_stage2_simpleae.py:78-93) or per-channel sequences (`sw_norm(...)`: dataset/Stage2_SW.py:74-105;
+    `twophase_norm(...)`: dataset/twophase_flow_stage2.py:304-337).  `param` [N] (one value per frame) is passed to a
+    ConditionalSimpleAutoencoder's encode."""
     frames = torch.as_tensor(frames)
     dev = next(iter(autoencoder.parameters())).device
+    C = frames.shape[1]
+
+    def stat(v):
+        if isinstance(v, (int, float)):
+            return float(v)
+        t = torch.as_tensor([float(e) for e in v], dtype=torch.float32, device=dev)
+        if t.numel() != C:
+            raise ValueError("per-channel statistics need %d entries" % C)
+        return t.reshape(1, C, 1, 1)
+    m, sd = stat(mean), stat(std)
+    if param is not None:
+        param = torch.as_tensor(param)
     outs = []
     for s in range(0, frames.shape[0], chunk):
         u = frames[s:s + chunk].to(dev, dtype=torch.float32)
-        u = (u - mean) / (std + 1e-8)
-        outs.append(autoencoder.encode(u).to(out_device))
+        u = (u - m) / (sd + eps)
+        z = autoencoder.encode(u) if param is None else autoencoder.encode(u, param[s:s + chunk].to(dev))
+        outs.append(z.to(out_device))
     return torch.cat(outs, 0)

@@ -19,14 +19,19 @@ def _host(t):
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
+_ACTS = {"silu": 1, "gelu": 2, "relu": 3, "tanh": 4, "sigmoid": 5}     # ACTIVATION_REGISTRY, modules/basics.py:10-16
+
+
 class _FourierBase(nn.Module):
-    def __init__(self, in_planes, planes, modes, residual=True, conditional=False):
+    def __init__(self, in_planes, planes, modes, residual=True, conditional=False, activation="gelu"):
         super().__init__()
         if len(modes) != 2:
-            raise NotImplementedError("only the 2-D block is on the accelerated path")
-        if in_planes != planes or not residual:
-            raise NotImplementedError("the accelerated block needs in_planes == planes and residual=True")
+            raise NotImplementedError("only the 2-D block is on the accelerated path (the hot path is 2-D, SURVEY 2.1)")
+        if residual and in_planes != planes:
+            raise ValueError("residual=True adds the input to the output: in_planes must equal planes")
         self.modes = list(modes)
+        self.in_planes, self.planes, self.residual = in_planes, planes, bool(residual)
+        self._act = _ACTS[activation]
         m1, m2 = modes
         scale = 1.0 / (in_planes * planes)
         self.fourier = _Node()
@@ -51,7 +56,9 @@ class _FourierBase(nn.Module):
             raise LnsError("HIP device fp32 tensors only (no CPU fallback)")
         x = x.contiguous()
         B, C, H, W = x.shape
-        y = torch.empty_like(x)
+        if C != self.in_planes:
+            raise LnsError("expected %d input channels, got %d" % (self.in_planes, C))
+        y = torch.empty((B, self.planes, H, W), dtype=torch.float32, device=x.device)
         keep = [_host(self.fourier.weights1), _host(self.fourier.weights2), _host(self.conv.weight), _host(self.conv.bias)]
         args = [k[1] for k in keep]
         cptr = None
@@ -63,10 +70,12 @@ class _FourierBase(nn.Module):
                   _host(self.cond_emb.bias)]
             keep += k2
             extra = [k[1] for k in k2]
-        rc = _lib.lib().lns_op_fourier_block(ctypes.c_void_p(x.data_ptr()), B, C, H, W, self.modes[0], self.modes[1],
-                                             args[0], args[1], args[2], args[3], cptr, extra[0], extra[1], extra[2],
-                                             extra[3], ctypes.c_void_p(y.data_ptr()),
-                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().lns_op_fourier_block(ctypes.c_void_p(x.data_ptr()), B, C, self.planes, H, W, self.modes[0],
+                                                 self.modes[1], args[0], args[1], args[2], args[3], cptr, extra[0],
+                                                 extra[1], extra[2], extra[3], self._act, int(self.residual),
+                                                 ctypes.c_void_p(y.data_ptr()),
+                                                 ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
             raise LnsError("lns_op_fourier_block failed (%d)" % rc)
         return y
@@ -74,9 +83,9 @@ class _FourierBase(nn.Module):
 
 class FourierBasicBlock(_FourierBase):
     def __init__(self, in_planes, planes, modes, activation="gelu", residual=True):
-        if activation != "gelu":
-            raise NotImplementedError("gelu only (the reference's default and only use)")
-        super().__init__(in_planes, planes, modes, residual, conditional=False)
+        if activation not in _ACTS:
+            raise NotImplementedError(f"Activation {activation} not implemented")
+        super().__init__(in_planes, planes, modes, residual, conditional=False, activation=activation)
 
     def forward(self, x):
         return self._run(x, None)

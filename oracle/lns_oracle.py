@@ -228,6 +228,18 @@ def hp_residual_block(net, x, pfx):
     return net.rec(pfx, h + skip)
 
 
+def cond_residual_block(net, x, pfx, cond_emb):
+    """CondResidualBlock.forward, norm=True (GroupNorm(1, C), eps 1e-5), GELU, use_scale_shift_norm=False:
+    modules/cond_utils.py:112-128"""
+    sd = net.sd
+    h = net.conv(gelu(net.gn(x, pfx + ".norm1", 1)), pfx + ".conv1")
+    e = linear(cond_emb, sd[pfx + ".cond_emb.weight"], sd[pfx + ".cond_emb.bias"])[:, :, None, None]
+    h = h + e
+    h = net.conv(gelu(net.gn(h, pfx + ".norm2", 1)), pfx + ".conv2")
+    sc = conv2d(x, sd[pfx + ".shortcut.weight"], sd[pfx + ".shortcut.bias"]) if net.has(pfx + ".shortcut.weight") else x
+    return net.rec(pfx, h + sc)
+
+
 def downsample_block(net, x, pfx):
     """modules/basics.py:302-328: F.pad then Conv2d(ch,ch,3,2,0)"""
     if net.mode == (CIRC, CIRC):
@@ -356,14 +368,30 @@ def spectral_conv2d(sd, pfx, x, emb12=None):
     return np.fft.irfft2(out_ft, s=(H, W)).astype(np.float32)
 
 
-def fourier_basic_block(net, x, pfx):
-    """modules/basics.py:574-583"""
+def activation(x, name):
+    """ACTIVATION_REGISTRY: modules/basics.py:10-16"""
+    if name == "gelu":
+        return gelu(x)
+    if name == "silu":
+        return swish(x)
+    if name == "relu":
+        return np.maximum(x, np.float32(0.0))
+    if name == "tanh":
+        return np.tanh(x).astype(np.float32)
+    if name == "sigmoid":
+        return (np.float32(1.0) / (np.float32(1.0) + np.exp(-x))).astype(np.float32)
+    raise NotImplementedError(name)
+
+
+def fourier_basic_block(net, x, pfx, act="gelu", residual=True):
+    """modules/basics.py:574-583 (in_planes != planes allowed when residual is False)"""
     x1 = spectral_conv2d(net.sd, pfx + ".fourier", x)
     x2 = conv2d(x, net.sd[pfx + ".conv.weight"], net.sd[pfx + ".conv.bias"])
-    return x + gelu(x1 + x2)
+    out = activation(x1 + x2, act)
+    return x + out if residual else out
 
 
-def cond_fourier_basic_block(sd, pfx, x, cond_emb):
+def cond_fourier_basic_block(sd, pfx, x, cond_emb, residual=True):
     """modules/fourier_cond.py:106-117 (+ FreqLinear :25-29)"""
     fw = sd[pfx + ".fourier.cond_emb.weights"]
     fb = sd[pfx + ".fourier.cond_emb.bias"]
@@ -374,7 +402,8 @@ def cond_fourier_basic_block(sd, pfx, x, cond_emb):
     x1 = spectral_conv2d(sd, pfx + ".fourier", x, emb12)
     x2 = conv2d(x, sd[pfx + ".conv.weight"], sd[pfx + ".conv.bias"])
     e = linear(cond_emb, sd[pfx + ".cond_emb.weight"], sd[pfx + ".cond_emb.bias"])
-    return x + gelu(x1 + x2 + e[:, :, None, None])
+    out = gelu(x1 + x2 + e[:, :, None, None])
+    return x + out if residual else out
 
 
 def fourier_embedding(t, dim, max_period=10000):
@@ -515,6 +544,33 @@ class OracleAutoencoder:
 # ----------------------------------------------------------------------------
 # propagators
 # ----------------------------------------------------------------------------
+class OracleCondAutoencoder(OracleAutoencoder):
+    """ConditionalSimpleAutoencoder: modules/autoencoder2d_nonsquared.py:279-305 (CondEncoder.forward :126-145)."""
+
+    def encode(self, x, param):
+        a, net, sd, p = self.args, self.net, self.net.sd, self.pfx + "encoder."
+        E = a.cond_emb_channels
+        ce = fourier_embedding(np.asarray(param), E)
+        ce = linear(ce, sd[p + "embed.0.weight"], sd[p + "embed.0.bias"])
+        ce = linear(swish(ce), sd[p + "embed.2.weight"], sd[p + "embed.2.bias"])
+        x = net.rec(p + "to_in.0", swish(conv2d(x, sd[p + "to_in.0.weight"], sd[p + "to_in.0.bias"])))
+        x = net.conv(x, p + "to_in.2")
+        n = len(a.encoder_channels)
+        for i in range(n - 1):
+            for j in range(a.encoder_res_blocks):
+                x = cond_residual_block(net, x, p + f"layers.{i}.0.{j}", ce)
+            if i != n - 2:
+                x = downsample_block(net, x, p + f"layers.{i}.1")
+        x = cond_residual_block(net, x, p + "to_out_conv", ce)
+        x = swish(net.gn32(x, p + "to_out.0"))
+        x = net.rec(p + "to_out.2", conv2d(x, sd[p + "to_out.2.weight"], sd[p + "to_out.2.bias"]))
+        q = self.pfx + "quant_conv"
+        return conv2d(x, sd[q + ".weight"], sd[q + ".bias"])
+
+    def forward(self, x, param):
+        return self.decode(self.encode(x, param))
+
+
 class OraclePropagator:
     """SimpleCNN of train_stage2_{ns2d,SW,twophase,twophase_conditional}.py"""
 
@@ -677,10 +733,27 @@ def teacher_forced_loss(dyn, z_in, z_out, param=None, loss_fn=smooth_l1_loss):
     return loss_fn(np.stack(preds, 1), z_out)
 
 
-def encode_dataset(ae, frames, chunk=32, mean=0.0, std=1.0):
-    """ns2d_fno_stage2_simpleae.py:81-93: normalise, encode `chunk` frames at a time."""
+def normalize_frames(frames, mean=0.0, std=1.0, eps=1e-8):
+    """Dataset normalisation ahead of encode_dataset: (u - mean) / (std + eps) with scalar statistics
+    (ns2d_fno_stage2_simpleae.py:78-79, eps 1e-8) or per-channel ones over [N,C,H,W] -- Stage2_SW.normalize
+    (dataset/Stage2_SW.py:74-78: u, v, pres, eps 0) and TwoPhaseFlow.normalize_data
+    (dataset/twophase_flow_stage2.py:304-313: both velocity channels by the velocity statistics, pressure by its own,
+    the VOF channel untouched, eps 0)."""
+    u = np.asarray(frames, np.float32)
+    m = np.asarray(mean, np.float32)
+    sd = np.asarray(std, np.float32)
+    if m.ndim == 1:
+        m = m.reshape(1, -1, 1, 1)
+    if sd.ndim == 1:
+        sd = sd.reshape(1, -1, 1, 1)
+    return ((u - m) / (sd + np.float32(eps))).astype(np.float32)
+
+
+def encode_dataset(ae, frames, chunk=32, mean=0.0, std=1.0, eps=1e-8, param=None):
+    """ns2d_fno_stage2_simpleae.py:81-93 / Stage2_SW.py:80-105 / twophase_flow_stage2.py:317-337: normalise, encode
+    `chunk` frames at a time (the two-phase dataset uses chunks of 32, the others one case per call)."""
     outs = []
     for s in range(0, frames.shape[0], chunk):
-        u = (frames[s:s + chunk].astype(np.float32) - np.float32(mean)) / (np.float32(std) + np.float32(1e-8))
-        outs.append(ae.encode(u.astype(np.float32)))
+        u = normalize_frames(frames[s:s + chunk], mean, std, eps)
+        outs.append(ae.encode(u) if param is None else ae.encode(u, np.asarray(param)[s:s + chunk]))
     return np.concatenate(outs, 0)

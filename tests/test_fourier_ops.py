@@ -60,3 +60,64 @@ def test_hip_fourier_blocks_match_reference(conditional):
     y = y.cpu().numpy()
     assert rel_l2(y, d[name + "_y"]) < 5e-6
     assert rel_l2(y, d[name + "_y_f64"]) < 5e-6
+
+
+def _gen_cases():
+    m, _ = _load()
+    return [g["name"] for g in m.get("general", [])]
+
+
+def _gen(m, name):
+    from lns_amd import filler
+    g = [e for e in m["general"] if e["name"] == name][0]
+    x = filler.normal("xop_" + name, (m["B"], g["cin"], m["H"], m["W"]), m["input_seed"])
+    cond = filler.normal("cop_" + name, (m["B"], g["cin"]), m["input_seed"])
+    return g, x, cond
+
+
+@pytest.mark.parametrize("name", _gen_cases())
+def test_oracle_general_fourier_blocks_match_reference(name):
+    """in_planes != planes, residual=False and the other ACTIVATION_REGISTRY entries (modules/basics.py:531-583)."""
+    import lns_oracle
+    m, d = _load()
+    g, x, cond = _gen(m, name)
+    sd = {"blk." + k: v for k, v in _weights(d[name + "_keys"], m["weight_seed"]).items()}
+    if g["cond"]:
+        y = lns_oracle.cond_fourier_basic_block(sd, "blk", x, cond, residual=g["residual"])
+    else:
+        y = lns_oracle.fourier_basic_block(lns_oracle._Net(sd, (0, 0)), x, "blk", act=g["act"], residual=g["residual"])
+    assert y.shape == d[name + "_y"].shape
+    assert rel_l2(y, d[name + "_y"]) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _gen_cases())
+def test_hip_general_fourier_blocks_match_reference(name):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from lns_amd.modules.fourier_cond import CondFourierBasicBlock, FourierBasicBlock
+    m, d = _load()
+    g, x, cond = _gen(m, name)
+    if g["cond"]:
+        blk = CondFourierBasicBlock(g["cin"], g["cout"], [m["m1"], m["m2"]], residual=g["residual"])
+    else:
+        blk = FourierBasicBlock(g["cin"], g["cout"], [m["m1"], m["m2"]], activation=g["act"], residual=g["residual"])
+    w = _weights(d[name + "_keys"], m["weight_seed"])
+    assert set(blk.state_dict()) == set(w)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    xd = torch.from_numpy(x).cuda()
+    y = blk(xd, torch.from_numpy(cond).cuda()) if g["cond"] else blk(xd)
+    y = y.cpu().numpy()
+    assert y.shape == d[name + "_y"].shape
+    assert rel_l2(y, d[name + "_y"]) < 5e-6
+    assert rel_l2(y, d[name + "_y_f64"]) < 5e-6
+
+
+def test_residual_needs_matching_planes():
+    pytest.importorskip("torch")
+    from lns_amd.modules.fourier_cond import FourierBasicBlock
+    with pytest.raises(ValueError):
+        FourierBasicBlock(4, 6, [2, 2], residual=True)
+    with pytest.raises(NotImplementedError):
+        FourierBasicBlock(4, 4, [2, 2], activation="softplus")

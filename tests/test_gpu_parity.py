@@ -420,3 +420,69 @@ def test_encode_dataset_matches_oracle():
     assert rel_l2(z, ref) < STAGE_TOL
     with pytest.raises(RuntimeError):
         metrics.relative_l2(torch.zeros(1, 1, 1, 2, 2), torch.zeros(1, 1, 1, 2, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,spec", [("sw_half_periodic", "sw"), ("twophase", "twophase")])
+def test_encode_dataset_per_channel_statistics(preset, spec):
+    """The other datasets' pre-encoding: per-channel normalisation (dataset/Stage2_SW.py:74-105: u / v / pres; dataset/
+    twophase_flow_stage2.py:304-337: velocities / pressure / VOF untouched, chunks of 32) + chunked encode, vs oracle."""
+    _need_gpu()
+    import gpu_checks as gc
+    import lns_oracle
+    from lns_amd import config, filler, metrics
+    args = config.preset(preset)
+    model, orc = gc.build_models(args, 1)
+    N = 5
+    raw = filler.normal("frames_" + spec, (N, args.in_channels, args.Ly, args.Lx), 9)
+    if spec == "sw":
+        kw = metrics.sw_norm(0.4, 2.1, -0.2, 1.7, 9.5, 0.6)
+        kw["chunk"] = 2
+    else:
+        kw = metrics.twophase_norm(0.013, 0.21, 310.0, 180.0)
+        raw[:, 3] = 0.5 + 0.3 * raw[:, 3]
+    # raw fields in physical units: x_phys = x * std + mean
+    m = np.asarray(kw["mean"], np.float32).reshape(1, -1, 1, 1)
+    sd = np.asarray(kw["std"], np.float32).reshape(1, -1, 1, 1)
+    frames = (raw * sd + m).astype(np.float32)
+    z = metrics.encode_dataset(model._ae, frames, **kw).numpy()
+    ref = lns_oracle.encode_dataset(orc.ae, frames, chunk=kw["chunk"], mean=kw["mean"], std=kw["std"], eps=kw["eps"])
+    assert z.shape == ref.shape == (N,) + tuple(model._engine(torch.zeros(1, device="cuda")).latent_shape())
+    assert rel_l2(z, ref) < STAGE_TOL
+    with pytest.raises(ValueError):
+        metrics.encode_dataset(model._ae, frames, mean=[0.0, 1.0], std=1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cond_ae_mini", "twophase_cond_ae"])
+def test_conditional_autoencoder_matches_reference_golden(case):
+    """ConditionalSimpleAutoencoder.encode(x, param) / decode / forward on the HIP engine vs the REAL
+    reference's outputs (tests/golden/<case>.npz) and vs the oracle; B=1 works; the unconditional entry point refuses."""
+    _need_gpu()
+    from helpers import manifest
+    from lns_amd import filler
+    from lns_amd._lib import LnsError
+    from lns_amd.modules.autoencoder2d_nonsquared import ConditionalSimpleAutoencoder
+    import lns_oracle
+    meta, g = load_golden(case)
+    args = case_args(meta)
+    sd = filler.synthetic_state_dict({k: tuple(v) for k, v in manifest()[case].items()}, meta["weight_seed"])
+    model = ConditionalSimpleAutoencoder(args)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    x = filler.normal("x", (meta["B"], args.in_channels, args.Ly, args.Lx), meta["input_seed"])
+    param = filler.uniform01("param", meta["B"], meta["input_seed"]).astype(np.float32)
+    xd, pd = torch.from_numpy(x).cuda(), torch.from_numpy(param).cuda()
+    z = model.encode(xd, pd)
+    y = model.decode(z)
+    sub = meta["sub"]
+    assert rel_l2(z.cpu().numpy(), g["z"]) < STAGE_TOL
+    assert rel_l2(y.cpu().numpy()[..., ::sub, ::sub], g["y"]) < STAGE_TOL * 2
+    assert rel_l2(z.cpu().numpy(), g["z_f64"]) < STAGE_TOL
+    assert torch.equal(model(xd, pd), y)
+    orc = lns_oracle.OracleCondAutoencoder(args, sd, "")
+    assert rel_l2(z.cpu().numpy(), orc.encode(x, param)) < STAGE_TOL
+    assert torch.equal(model.encode(xd[1:2].contiguous(), pd[1:2].contiguous()), z[1:2])      # batch-independent, B = 1
+    assert rel_l2(model.encode(xd, pd.flip(0)).cpu().numpy(), g["z"]) > 1e-3                   # conditioning is live
+    with pytest.raises((LnsError, TypeError)):
+        model._engine(xd).encode(xd)                                                           # param is required

@@ -167,14 +167,85 @@ def make_op_goldens():
         out[name + "_y_f64"] = y64.astype(np.float32)
         out[name + "_keys"] = np.array(sorted("%s:%s" % (k, "x".join(map(str, v.shape)))
                                               for k, v in blk.state_dict().items()))
-    meta = dict(B=B, C=C, H=H, W=W, m1=m1, m2=m2, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED)
+    # general forms (basics.py:531-583): in_planes != planes with residual=False, the other registry activations
+    gen = [("gen_6_10_gelu", 6, 10, "gelu", False, False), ("gen_8_8_silu_nores", 8, 8, "silu", False, False),
+           ("gen_8_8_relu", 8, 8, "relu", True, False), ("gen_5_3_tanh", 5, 3, "tanh", False, False),
+           ("gen_4_4_sigmoid", 4, 4, "sigmoid", True, False), ("gen_cond_6_10", 6, 10, "gelu", False, True)]
+    for name, ci, co, act, res, cnd in gen:
+        xg = filler.normal("xop_" + name, (B, ci, H, W), INPUT_SEED)
+        cg = filler.normal("cop_" + name, (B, ci), INPUT_SEED)
+        if cnd:
+            blk = mods["modules.fourier_cond"].CondFourierBasicBlock(ci, co, modes=[m1, m2], residual=res)
+            extra = (torch.from_numpy(cg),)
+        else:
+            blk = mods["modules.basics"].FourierBasicBlock(ci, co, modes=[m1, m2], activation=act, residual=res)
+            extra = ()
+        filler.load_into_torch_module(blk, WEIGHT_SEED)
+        blk.eval()
+        with torch.no_grad():
+            y = blk(torch.from_numpy(xg), *extra).numpy()
+            y64 = blk.double()(torch.from_numpy(xg).double(), *[e.double() for e in extra]).numpy()
+        out[name + "_y"] = y.astype(np.float32)
+        out[name + "_y_f64"] = y64.astype(np.float32)
+        out[name + "_keys"] = np.array(sorted("%s:%s" % (k, "x".join(map(str, v.shape)))
+                                              for k, v in blk.state_dict().items()))
+    meta = dict(B=B, C=C, H=H, W=W, m1=m1, m2=m2, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED,
+                general=[dict(name=n, cin=ci, cout=co, act=a, residual=r, cond=c) for n, ci, co, a, r, c in gen])
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "ops_fourier.npz"), **out)
     print("ops_fourier written")
 
 
+COND_AE_CASES = {"cond_ae_mini": ("cond_ae_mini", 1), "twophase_cond_ae": ("twophase_cond_ae", 3)}
+
+
+def make_cond_ae_goldens():
+    """ConditionalSimpleAutoencoder (modules/autoencoder2d_nonsquared.py:279-305): encode(x, param) -> z,
+    decode(z) -> y of the REAL reference on filler weights (zero_module tensors non-zero), fp32 and fp64."""
+    import ref_shim
+    mods = ref_shim.load_reference()
+    man_path = os.path.join(OUT, "state_dict_manifest.json")
+    with open(man_path) as f:
+        man = json.load(f)
+    for name, (preset, sub) in COND_AE_CASES.items():
+        args = config.preset(preset)
+        B = 2
+        x, _ = make_inputs(args, B)
+        param = filler.uniform01("param", B, INPUT_SEED).astype(np.float32)
+        out = {}
+        for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+            model = mods["modules.autoencoder2d_nonsquared"].ConditionalSimpleAutoencoder(args)
+            filler.load_into_torch_module(model, WEIGHT_SEED)
+            model = model.to(dt).eval()
+            if dt == torch.float64:
+                # cond_utils.fourier_embedding casts to fp32 (`.float()`, :34): re-cast for the fp64 tie-breaker
+                m = mods["modules.autoencoder2d_nonsquared"]
+                orig = m.fourier_embedding
+                m.fourier_embedding = lambda t, dim, max_period=10000, _o=orig: _o(t, dim, max_period).to(t.dtype)
+            with torch.no_grad():
+                z = model.encode(torch.from_numpy(x).to(dt), torch.from_numpy(param).to(dt))
+                y = model.decode(z)
+                assert torch.equal(model(torch.from_numpy(x).to(dt), torch.from_numpy(param).to(dt)), y)
+            if dt == torch.float64:
+                m.fourier_embedding = orig
+            out["z" + tag] = z.numpy().astype(np.float32)
+            out["y" + tag] = y.numpy()[..., ::sub, ::sub].astype(np.float32)
+            out["y_norm" + tag] = np.sqrt((y.numpy().astype(np.float64) ** 2).sum((-1, -2)))
+        man[name] = {k: list(v.shape) for k, v in model.state_dict().items()}
+        meta = dict(case=name, preset=preset, overrides={}, B=B, sub=sub, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED,
+                    n_tensors=len(model.state_dict()), kind="cond_ae")
+        out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "written", {k: v.shape for k, v in out.items() if k != "meta"})
+    with open(man_path, "w") as f:
+        json.dump(man, f, indent=0, sort_keys=False)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(CASES) + ["ops"]
+    which = sys.argv[1:] or list(CASES) + ["ops", "cond_ae"]
+    if "cond_ae" in which:
+        which.remove("cond_ae")
+        make_cond_ae_goldens()
     if "ops" in which:
         which.remove("ops")
         make_op_goldens()

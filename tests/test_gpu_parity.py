@@ -492,10 +492,13 @@ def test_conditional_autoencoder_matches_reference_golden(case):
 def test_packed_fp32_corun():
     """Regression guard of the co-residency finding: the product is built without packed-fp32 VALU
     instructions (CPU test test_device_code_has_no_packed_fp32_arithmetic); this runs the standalone reproducer
-    (tools/pk_hazard: v_pk_fma_f32 with op_sel vs scalar v_fma_f32 in the SAME wave, alone and beside an MFMA-dense kernel
-    on a second stream).  What must hold: the scalar form -- the one the product uses -- never differs from itself.  The
-    packed counts are reported (printed, recorded in DESIGN.md): on the boxes of round 1 the engine-level pair stress saw
-    mismatches only with packed instructions and only under co-residency."""
+    (tools/pk_hazard: the exact v_pk_fma_f32 ... op_sel pair hipcc emitted in the fp32 1x1 kernel vs scalar v_fma_f32 in
+    the SAME wave, alone and beside an MFMA-dense kernel on a second stream).  What must hold: the scalar form -- the one
+    the product uses -- never differs from itself.  The packed counts are reported: the minimal pair does NOT reproduce
+    the corruption (0 in 1.7e9 words, profiles/r02_pk_hazard_standalone.log), while the engine-level pair stress does as
+    soon as the CURRENT kernels are built with packed-fp32 ops (profiles/r02_pair_stress_packed_build.log: 1024..25600
+    wrong words on the fp32 1x1 side next to a 16-bit-MFMA kernel, 0 for fp32 | fp32 pairs) and never with the shipped
+    build (profiles/r02_pair_stress_shipped_build.log)."""
     _need_gpu()
     import os
     import sys

@@ -37,11 +37,15 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ x
         const float2 st = ssl[c];
         float r0, r1, r2, r3;
         if (PACKED) {
-            f32x2 a = {v.x, v.y}, b = {v.z, v.w}, s = {st.x, st.y}, o0, o1;
-            asm volatile("v_pk_fma_f32 %0, %2, %4, %4 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
-                         "v_pk_fma_f32 %1, %3, %4, %4 op_sel:[0,0,1] op_sel_hi:[1,0,1]"
-                         : "=&v"(o0), "=&v"(o1) : "v"(a), "v"(b), "v"(s));
-            r0 = o0[0]; r1 = o0[1]; r2 = o1[0]; r3 = o1[1];
+            // exactly the pair hipcc emitted in the fp32 1x1 kernel: the SECOND instruction's destination is the
+            // (scale, shift) register pair it also reads through op_sel
+            //     v_pk_fma_f32 v[6:7], v[82:83], v[2:3], v[2:3] op_sel:[0,0,1] op_sel_hi:[1,0,1]
+            //     v_pk_fma_f32 v[2:3], v[84:85], v[2:3], v[2:3] op_sel:[0,0,1] op_sel_hi:[1,0,1]
+            f32x2 a = {v.x, v.y}, b = {v.z, v.w}, s = {st.x, st.y}, o0;
+            asm volatile("v_pk_fma_f32 %0, %2, %1, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+                         "v_pk_fma_f32 %1, %3, %1, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]"
+                         : "=&v"(o0), "+v"(s) : "v"(a), "v"(b));
+            r0 = o0[0]; r1 = o0[1]; r2 = s[0]; r3 = s[1];
         } else {
             r0 = sfma(v.x, st.x, st.y); r1 = sfma(v.y, st.x, st.y); r2 = sfma(v.z, st.x, st.y); r3 = sfma(v.w, st.x, st.y);
         }

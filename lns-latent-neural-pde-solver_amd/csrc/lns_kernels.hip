@@ -3014,16 +3014,19 @@ __device__ __forceinline__ void split3_scalar(float x, unsigned short& h, unsign
 
 // FULL: H == 32 HT and W == 32 WT (the 32x32 and 64x64 planes of NS2d): the validity masks of the partial-tile form
 // drop out at compile time (same additions in the same order: both forms agree bit for bit on such planes).
-template <int HT, int WT, bool VEC, bool FULL = false>
-__global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a, int planes_per_block) {
+// NWV: waves per block (4; 3 where the LDS image of four private P bands does not fit: 48x96 planes).
+// ULOOP: one column tile of U at a time (P fragments re-read per tile) instead of all WT at once -- the same
+// additions in the same order, a third of the U / Ky-fragment registers: no spills on the 2x3-tile planes.
+template <int HT, int WT, bool VEC, bool FULL = false, int NWV = 4, bool ULOOP = false>
+__global__ __launch_bounds__(64 * NWV, 1) void fa_sandwich_b_kernel(FaSandwichArgs a, int planes_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HB = HT * 32, WB = WT * 32;
+    constexpr int HB = HT * 32, WB = WT * 32, NTHR = 64 * NWV;
     constexpr int KXW = HB + 8, KYW = WB + 8;               // row strides in bf16 elements
     constexpr int NPH = 32 * WB / 64;                       // plane floats per lane per 32-row band
     constexpr int NQH = VEC ? NPH / 4 : NPH;
     unsigned short* Kxs = reinterpret_cast<unsigned short*>(smem);      // [3][HB][KXW]
     unsigned short* Kys = Kxs + 3 * HB * KXW;                           // [3][WB][KYW]
-    unsigned short* Pall = Kys + 3 * WB * KYW;                          // 4 x [3][32][KYW]
+    unsigned short* Pall = Kys + 3 * WB * KYW;                          // NWV x [3][32][KYW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int H = a.H, W = a.W, C = a.C;
@@ -3031,21 +3034,22 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
     const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
     const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
     {   // Kx (column-permuted) and Ky, split, all loads of a thread in flight at once
-        constexpr int NX = HB * HB / 256, NY = WB * WB / 256;
+        constexpr int NX = (HB * HB + NTHR - 1) / NTHR, NY = (WB * WB + NTHR - 1) / NTHR;
         float vx[NX], vy[NY];
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            const int i = tid + u * 256, r = i / HB, c = i - r * HB;
-            vx[u] = (r < H && c < H) ? kxg[(long)r * H + c] : 0.0f;
+            const int i = tid + u * NTHR, r = i / HB, c = i - r * HB;
+            vx[u] = (r < H && c < H) ? kxg[(long)r * H + c] : 0.0f;      // (r >= HB past the end of a ragged last slot: r >= H too)
         }
 #pragma unroll
         for (int u = 0; u < NY; ++u) {
-            const int i = tid + u * 256, r = i / WB, c = i - r * WB;
+            const int i = tid + u * NTHR, r = i / WB, c = i - r * WB;
             vy[u] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            const int i = tid + u * 256, r = i / HB, c = i - r * HB;
+            const int i = tid + u * NTHR, r = i / HB, c = i - r * HB;
+            if (i >= HB * HB) continue;
             const int w = c & 15;
             const int cp = (c & ~15) | (w & 3) | (((w >> 3) & 1) << 2) | (((w >> 2) & 1) << 3);
             unsigned short hh, mm, ll;
@@ -3054,7 +3058,8 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
         }
 #pragma unroll
         for (int u = 0; u < NY; ++u) {
-            const int i = tid + u * 256, r = i / WB, c = i - r * WB;
+            const int i = tid + u * NTHR, r = i / WB, c = i - r * WB;
+            if (i >= WB * WB) continue;
             unsigned short hh, mm, ll;
             split3_scalar(vy[u], hh, mm, ll);
             Kys[(0 * WB + r) * KYW + c] = hh; Kys[(1 * WB + r) * KYW + c] = mm; Kys[(2 * WB + r) * KYW + c] = ll;
@@ -3100,7 +3105,7 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
     const char* pa = reinterpret_cast<const char*>(Ps) + (l31 * KYW + 8 * kh) * 2;                  // + s*32*KYW*2 + t*32
     const char* kyb = reinterpret_cast<const char*>(Kys) + (l31 * KYW + 8 * kh) * 2;                // + (s*WB + lt*32)*KYW*2 + t*32
     const char* kxa = reinterpret_cast<const char*>(Kxs) + (l31 * KXW + 8 * kh) * 2;                // + (s*HB + it*32)*KXW*2 + (jt*32+16t')*2
-    for (; c < c_end; c += 4) {
+    for (; c < c_end; c += NWV) {
         f32x16 Yh[HT][WT], Yl[HT][WT];
 #pragma unroll
         for (int i = 0; i < HT; ++i)
@@ -3132,26 +3137,30 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
             }
             __builtin_amdgcn_wave_barrier();
             if (jt + 1 < HT) prefetch(a.u + (plane0 + c) * H * W, jt + 1);
-            else if (c + 4 < c_end) prefetch(a.u + (plane0 + c + 4) * H * W, 0);
+            else if (c + NWV < c_end) prefetch(a.u + (plane0 + c + NWV) * H * W, 0);
             // U[j][l] = sum_m P[j][m] Ky[l][m] for all WT column tiles at once: the P fragments are read once
-            // per k-step and consecutive MFMAs go to different accumulators (no dependent back-to-back issue)
-            f32x16 Uh[WT], Ul[WT];
+            // per k-step and consecutive MFMAs go to different accumulators (no dependent back-to-back issue).
+            // ULOOP: the same per column tile (UT = 1 tile in flight), see the template comment.
+            constexpr int UT = ULOOP ? 1 : WT;
 #pragma unroll
-            for (int lt = 0; lt < WT; ++lt)
+            for (int l0 = 0; l0 < WT; l0 += UT) {
+            f32x16 Uh[UT], Ul[UT];
+#pragma unroll
+            for (int lt = 0; lt < UT; ++lt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { Uh[lt][r] = 0.0f; Ul[lt][r] = 0.0f; }
 #pragma unroll
             for (int t = 0; t < WB / 16; ++t) {
-                bf16x8 A[3], Bq[WT][3];
+                bf16x8 A[3], Bq[UT][3];
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     A[s] = *reinterpret_cast<const bf16x8*>(pa + s * (32 * KYW * 2) + t * 32);
 #pragma unroll
-                    for (int lt = 0; lt < WT; ++lt)
-                        Bq[lt][s] = *reinterpret_cast<const bf16x8*>(kyb + (s * WB + lt * 32) * (KYW * 2) + t * 32);
+                    for (int lt = 0; lt < UT; ++lt)
+                        Bq[lt][s] = *reinterpret_cast<const bf16x8*>(kyb + (s * WB + (l0 + lt) * 32) * (KYW * 2) + t * 32);
                 }
 #define LNS_SWU(ACC, SA, SB)                                                                          \
-    _Pragma("unroll") for (int lt = 0; lt < WT; ++lt)                                                 \
+    _Pragma("unroll") for (int lt = 0; lt < UT; ++lt)                                                 \
         ACC[lt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], Bq[lt][SB], ACC[lt], 0, 0, 0);
                 LNS_SWU(Ul, 1, 1)
                 LNS_SWU(Uh, 0, 0)
@@ -3162,7 +3171,8 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
 #undef LNS_SWU
             }
 #pragma unroll
-            for (int lt = 0; lt < WT; ++lt) {
+            for (int ul = 0; ul < UT; ++ul) {
+                const int lt = l0 + ul;
                 // split U in registers: k-step t' of the second product takes registers 8t'..8t'+7
                 uint4 Bu[2][3];
 #pragma unroll
@@ -3170,8 +3180,8 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
                     unsigned hq[4], mq[4], lq[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        split3_pair(Uh[lt][8 * tp + 2 * e] + Ul[lt][8 * tp + 2 * e],
-                                    Uh[lt][8 * tp + 2 * e + 1] + Ul[lt][8 * tp + 2 * e + 1], hq[e], mq[e], lq[e]);
+                        split3_pair(Uh[ul][8 * tp + 2 * e] + Ul[ul][8 * tp + 2 * e],
+                                    Uh[ul][8 * tp + 2 * e + 1] + Ul[ul][8 * tp + 2 * e + 1], hq[e], mq[e], lq[e]);
                     Bu[tp][0] = make_uint4(hq[0], hq[1], hq[2], hq[3]);
                     Bu[tp][1] = make_uint4(mq[0], mq[1], mq[2], mq[3]);
                     Bu[tp][2] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
@@ -3199,6 +3209,7 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
 #undef LNS_SWY
                 }
             }
+            }   // l0
         }
 #pragma unroll
         for (int it = 0; it < HT; ++it)
@@ -3245,9 +3256,12 @@ __global__ __launch_bounds__(256, 1) void fa_sandwich_b_kernel(FaSandwichArgs a,
     }
 }
 
-static size_t fa_sandwich_b_lds_bytes(int HT, int WT) {
+constexpr size_t fa_sandwich_b_lds_const(int HT, int WT, int nwv) {
+    return ((size_t)3 * HT * 32 * (HT * 32 + 8) + (size_t)3 * WT * 32 * (WT * 32 + 8) + (size_t)nwv * 3 * 32 * (WT * 32 + 8)) * 2;
+}
+static size_t fa_sandwich_b_lds_bytes(int HT, int WT, int nwv = 4) {
     const size_t HB = HT * 32, WB = WT * 32;
-    return (3 * HB * (HB + 8) + 3 * WB * (WB + 8) + 4 * 3 * 32 * (WB + 8)) * 2;
+    return (3 * HB * (HB + 8) + 3 * WB * (WB + 8) + (size_t)nwv * 3 * 32 * (WB + 8)) * 2;
 }
 
 size_t fa_sandwich_lds_bytes(int H, int W) {
@@ -3260,19 +3274,26 @@ template <int HT, int WT>
 static hipError_t launch_fa_sandwich_t(const FaSandwichArgs& a, hipStream_t s) {
     // bf16x3 form whenever its LDS image fits (a function of H, W only, so the choice never depends on the batch)
     static const bool fp32_only = getenv("LNS_FA_SANDWICH_FP32") != nullptr;
-    if (!fp32_only && fa_sandwich_b_lds_bytes(HT, WT) <= 160 * 1024) {
+    // Four waves per block.  Where four private P bands do not fit the LDS (48x96 planes of the SW decoder: 167 KB) the
+    // three-wave form of the bf16x3 kernel exists (NWV = 3, per-tile U) but measured SLOWER than the fp32-MFMA kernel
+    // below (SW 96x192x5, B=64: sandwich class 82.0 vs 69.8 ms per rollout -- 46 spilled registers, three waves per CU),
+    // so LNS_FA_SANDWICH_3WAVE opts in and the default for those planes stays fp32 MFMA.
+    static const bool three_wave = getenv("LNS_FA_SANDWICH_3WAVE") != nullptr;
+    constexpr int NWV = fa_sandwich_b_lds_const(HT, WT, 4) <= 160 * 1024 ? 4 : 3;
+    constexpr bool UL = HT * WT >= 6;
+    if (!fp32_only && (NWV == 4 || three_wave) && fa_sandwich_b_lds_bytes(HT, WT, NWV) <= 160 * 1024) {
         // planes per block: the Kx/Ky staging (load + split) is paid once per block, so as many planes as still leave
         // >= 2 blocks per CU
         static const int ppb_max = getenv("LNS_FA_PPB") ? atoi(getenv("LNS_FA_PPB")) : 64;
         int ppb = ppb_max;
         while (ppb > 4 && (long)a.B * a.heads * ((a.C + ppb - 1) / ppb) < 512) ppb >>= 1;
         dim3 grid((a.C + ppb - 1) / ppb, a.heads, a.B);
-        const size_t ldsb = fa_sandwich_b_lds_bytes(HT, WT);
+        const size_t ldsb = fa_sandwich_b_lds_bytes(HT, WT, NWV);
         const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.u) & 15) == 0);
         if (vec && HT == WT && a.H == HT * 32 && a.W == WT * 32)       // layer-static: the shape decides, never the batch
-            hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true, (HT == WT)>), grid, dim3(256), ldsb, s, a, ppb);
-        else if (vec) hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true>), grid, dim3(256), ldsb, s, a, ppb);
-        else hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, false>), grid, dim3(256), ldsb, s, a, ppb);
+            hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true, (HT == WT), NWV, UL>), grid, dim3(64 * NWV), ldsb, s, a, ppb);
+        else if (vec) hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, true, false, NWV, UL>), grid, dim3(64 * NWV), ldsb, s, a, ppb);
+        else hipLaunchKernelGGL((fa_sandwich_b_kernel<HT, WT, false, false, NWV, UL>), grid, dim3(64 * NWV), ldsb, s, a, ppb);
         return hipGetLastError();
     }
     const size_t lds = fa_sandwich_lds_bytes(a.H, a.W);
@@ -3699,18 +3720,16 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 3, false, 8>))
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, true, 16>))
     LNS_SET_LDS((conv_mfma_kernel<1, 1, 1, 4, 1, false, 16>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, true>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, true, true>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<2, 2, true, true>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<1, 1, false>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<1, 2, true>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<1, 2, false>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<2, 1, true>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<2, 1, false>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<2, 2, true>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<2, 2, false>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<2, 3, true>))
-    LNS_SET_LDS((fa_sandwich_b_kernel<2, 3, false>))
+#define LNS_SET_SWB(HT, WT)                                                                                              \
+    {                                                                                                                    \
+        constexpr int NWV = fa_sandwich_b_lds_const(HT, WT, 4) <= 160 * 1024 ? 4 : 3;                                    \
+        constexpr bool UL = HT * WT >= 6;                                                                                \
+        LNS_SET_LDS((fa_sandwich_b_kernel<HT, WT, true, (HT == WT), NWV, UL>))                                           \
+        LNS_SET_LDS((fa_sandwich_b_kernel<HT, WT, true, false, NWV, UL>))                                                \
+        LNS_SET_LDS((fa_sandwich_b_kernel<HT, WT, false, false, NWV, UL>))                                               \
+    }
+    LNS_SET_SWB(1, 1) LNS_SET_SWB(1, 2) LNS_SET_SWB(2, 1) LNS_SET_SWB(2, 2) LNS_SET_SWB(2, 3)
+#undef LNS_SET_SWB
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))

@@ -14,8 +14,10 @@ preset = sys.argv[1] if len(sys.argv) > 1 else "ns2d_128"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 R = int(sys.argv[4]) if len(sys.argv) > 4 else 5
-ARMS = [dict(decode_group=g, decode_streams=s, prop_priority=p)
-        for g in (1, 2, 4) for s in (2, 3) for p in (0, 1)]
+GROUPS = [int(v) for v in os.environ.get("SWEEP_GROUPS", "1,2,4").split(",")]
+STREAMS = [int(v) for v in os.environ.get("SWEEP_STREAMS", "2,3").split(",")]
+PRIOS = [int(v) for v in os.environ.get("SWEEP_PRIO", "0").split(",")]
+ARMS = [dict(decode_group=g, decode_streams=s, prop_priority=p) for g in GROUPS for s in STREAMS for p in PRIOS]
 args, model, sd = bench.build_model(preset, torch.device("cuda", 0))
 x = torch.from_numpy(filler.normal("x", (B, args.in_channels, args.Ly, args.Lx), 5)).cuda()
 param = torch.from_numpy(filler.uniform01("p", B, 5).astype("float32")).cuda() if args.family == "twophase_cond" else None

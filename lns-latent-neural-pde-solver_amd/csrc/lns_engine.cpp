@@ -455,7 +455,7 @@ struct Planner {
         if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
-        a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / pk.wscale : 1.0f;   // x 1/S in the kernel
+        a.unscale = (cv_is_f16x2_3x3(g.variant) || g.variant == CV_B1) ? 1.0f / pk.wscale : 1.0f;   // x 1/S in the kernel
         if (in.ss != 0 && in.gn_bound > 0.0f) { a.amax_in_const = in.gn_bound; a.bound_final = 1; }   // GroupNorm output: layer constant
         else {
             a.amax_in = as_ptr<const unsigned>(in.amax); a.amax_in_const = in.amax_const;
@@ -1869,16 +1869,16 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     pack_conv_weight(hw.data(), w_host, 0, Cout, Cin, ksize, pk.Cin_pad, pk.Cout_pad);
     if (bias_host) memcpy(hw.data() + wcount, bias_host, (size_t)Cout * 4);
     float wscale = 1.0f;
-    if (g.variant == CV_F64 || g.variant == CV_F32 || (g.variant == CV_B1 && convb1_is_f16())) {
+    if (cv_is_f16x2_3x3(g.variant) || (g.variant == CV_B1 && convb1_is_f16())) {
         float mx = 0.0f;
         for (size_t i = 0; i < (size_t)Cout * Cin * ksize * ksize; ++i) mx = std::max(mx, fabsf(w_host[i]));
         if (mx > 0.0f) wscale = exp2f(floorf(log2f(16000.0f / mx)));
     }
-    const size_t wb_floats = (g.variant == CV_B64 || g.variant == CV_B32 || g.variant == CV_F64 || g.variant == CV_F32) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
+    const size_t wb_floats = cv_is_split_3x3(g.variant) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
                            : g.variant == CV_B1 ? convb1_weight_bytes(Cout, pk.Cin_pad) / 4 : 0;
     if (wb_floats) {
         hw.resize(hw.size() + wb_floats, 0.0f);
-        if (g.variant == CV_F64 || g.variant == CV_F32) convf_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
+        if (cv_is_f16x2_3x3(g.variant)) convf_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
         else if (g.variant != CV_B1) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
         else convb1_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
     }
@@ -1897,7 +1897,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
-    a.unscale = (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) ? 1.0f / wscale : 1.0f;
+    a.unscale = (cv_is_f16x2_3x3(g.variant) || g.variant == CV_B1) ? 1.0f / wscale : 1.0f;
     // the input's per-sample maximum, as the producing kernel of a plan would have recorded it
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.damax), (size_t)B * LNS_AMAX_SUB * 4));
     OPCHK(hipMemset(oc.damax, 0, (size_t)B * LNS_AMAX_SUB * 4));
@@ -1925,8 +1925,34 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     if (rc) { oc.release(); return rc; }
     oc.a.amax_out = oc.variant == CV_THIN ? nullptr : amax_out;   // the thin final projection records none
     hipStream_t s = static_cast<hipStream_t>(stream);
+#ifdef LNS_TS
+    // diagnostic build: per-block phase timestamps of the split-operand 3x3 kernel, appended to $LNS_TS_FILE
+    const long nblk = (long)oc.a.tiles_x * oc.a.tiles_y * oc.a.cout_tiles * oc.a.B;
+    long long* dts = nullptr;
+    if (getenv("LNS_TS_FILE") && cv_is_split_3x3(oc.variant)) {
+        OPCHK(hipMalloc(reinterpret_cast<void**>(&dts), nblk * 64));
+        OPCHK(hipMemset(dts, 0, nblk * 64));
+    }
+    oc.a.dbg_ts = dts;
+#endif
     OPCHK(launch_conv(oc.variant, oc.a, s));
     OPCHK(hipStreamSynchronize(s));
+#ifdef LNS_TS
+    if (dts) {
+        std::vector<long long> h(nblk * 8);
+        OPCHK(hipMemcpy(h.data(), dts, nblk * 64, hipMemcpyDeviceToHost));
+        hipFree(dts);
+        if (FILE* f = fopen(getenv("LNS_TS_FILE"), "a")) {
+            fprintf(f, "# launch B=%d Cin=%d Cout=%d H=%d W=%d blocks=%ld\n", B, Cin, Cout, Hv, Wv, nblk);
+            for (long i = 0; i < nblk; ++i) {
+                fprintf(f, "%ld", i);
+                for (int k = 0; k < 8; ++k) fprintf(f, " %lld", h[i * 8 + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+#endif
     oc.release();
     return LNS_OK;
 }

@@ -69,6 +69,9 @@ struct ConvArgs {
     // function of the layer only), the kernel uses it as is -- no per-sample maximum, no reduction in the prologue
     int bound_final;
     unsigned* amax_out;    // [B] or null: atomic max of the bit patterns of |y| over everything this launch stores
+#ifdef LNS_TS
+    long long* dbg_ts;     // diagnostic build only: [blocks][8] phase timestamps (100 MHz wall clock) + hardware ids
+#endif
 };
 // power-of-two activation scale from a bound on |x| (host mirror of the device rule; tests)
 float convf_scale_for_bound(float bound);
@@ -79,7 +82,10 @@ enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4,
                    CV_B32 = 9 /* bf16x3 3x3 kernel, 32 couts x 128 pixels (same bits as CV_B64) */,
                    CV_F64 = 11 /* 3x3 kernel with the two-term fp16 split (f16x2), 64 couts x 128 pixels */,
                    CV_THIN = 12 /* streaming 1x1 projection to <= 4 output channels (VALU, HBM-bound) */,
-                   CV_F32 = 13 /* f16x2 3x3 kernel, 32 couts x 128 pixels (same bits as CV_F64) */ };
+                   CV_F32 = 13 /* f16x2 3x3 kernel, 32 couts x 128 pixels (same bits as CV_F64) */,
+                   CV_F256 = 14 /* f16x2 3x3 kernel, 64 couts x 256 pixels: a wave owns 64 couts x 64 pixels (same bits as CV_F64) */ };
+inline bool cv_is_f16x2_3x3(int v) { return v == CV_F64 || v == CV_F32 || v == CV_F256; }
+inline bool cv_is_split_3x3(int v) { return v == CV_B64 || v == CV_B32 || cv_is_f16x2_3x3(v); }
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
 size_t conv_lds_bytes(int variant, const ConvArgs& a);
@@ -94,7 +100,7 @@ hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 #define CONVF_TARGET_EXP 14
 #define LNS_AMAX_SUB 16
 #define CONVB_SLAB_BYTES 27648           // one (cout tile, stage) weight slab: 3 splits x 9 taps x 64 couts x 8 ch bf16
-size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits);
+size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits, int ring);
 bool convb_fits(const ConvArgs& a);
 hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s);
 // host-side packing of one [Cout][Cin][3][3] weight (cout offset co0 inside the pack) into the bf16x3 slab layout

@@ -1927,9 +1927,9 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
 #ifdef LNS_TS
     // diagnostic build: per-block phase timestamps of the split-operand 3x3 kernel, appended to $LNS_TS_FILE
-    const long nblk = (long)oc.a.tiles_x * oc.a.tiles_y * oc.a.cout_tiles * oc.a.B;
+    const long nblk = (long)oc.a.tiles_x * oc.a.tiles_y * oc.a.cout_tiles * oc.a.B;     // an upper bound for the input-stationary 1x1 form
     long long* dts = nullptr;
-    if (getenv("LNS_TS_FILE") && cv_is_split_3x3(oc.variant)) {
+    if (getenv("LNS_TS_FILE") && (cv_is_split_3x3(oc.variant) || oc.variant == CV_B1)) {
         OPCHK(hipMalloc(reinterpret_cast<void**>(&dts), nblk * 64));
         OPCHK(hipMemset(dts, 0, nblk * 64));
     }
@@ -1941,7 +1941,7 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
     if (dts) {
         std::vector<long long> h(nblk * 8);
         OPCHK(hipMemcpy(h.data(), dts, nblk * 64, hipMemcpyDeviceToHost));
-        hipFree(dts);
+        (void)hipFree(dts);
         if (FILE* f = fopen(getenv("LNS_TS_FILE"), "a")) {
             fprintf(f, "# launch B=%d Cin=%d Cout=%d H=%d W=%d blocks=%ld\n", B, Cin, Cout, Hv, Wv, nblk);
             for (long i = 0; i < nblk; ++i) {

@@ -724,6 +724,27 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
+// Diagnostic build (-DLNS_TS): per-block phase timestamps (100 MHz wall clock) of the split-operand kernels, written to
+// ConvArgs::dbg_ts [blocks][8]: entry, tables published, loop start, loop end, stores issued, stores acknowledged,
+// HW_ID, XCC_ID (tools/ts_analyze.py).  Expands to nothing in the shipped library.
+#ifdef LNS_TS
+#define LNS_TS_DECL long long ts_[6] = {0, 0, 0, 0, 0, 0};
+#define LNS_TSTAMP(i) { __builtin_amdgcn_sched_barrier(0); ts_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+#define LNS_TS_DUMP                                                                                   \
+    __builtin_amdgcn_s_waitcnt(0);                                                                    \
+    LNS_TSTAMP(5)                                                                                     \
+    if (a.dbg_ts && threadIdx.x == 0) {                                                               \
+        long long* d_ = a.dbg_ts + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;                   \
+        for (int i_ = 0; i_ < 6; ++i_) d_[i_] = ts_[i_];                                              \
+        d_[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                            \
+        d_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                           \
+    }
+#else
+#define LNS_TS_DECL
+#define LNS_TSTAMP(i)
+#define LNS_TS_DUMP
+#endif
+
 // Shared epilogue of the bf16x3 kernels (64-cout tile, wave = 64 couts x 32*NT pixels): sums the two
 // accumulators, then bias / per-sample add / activation / fused second 1x1 conv (fp32 MFMA, the
 // accumulator tile as B operand, see conv_mfma_kernel) / residual, and the coalesced stores.
@@ -733,7 +754,7 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 template <int NT, bool FUSE2, int MT = 2>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
-                                               float xinv, unsigned& am, const float* addv = nullptr) {
+                                               float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1) {
     constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
     static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
     f32x16 acc[MT][NT];
@@ -949,6 +970,33 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = acc[mt][nt][r];
         }
+    } else if (kFastStore && ybytes < (1L << 31)) {
+        // Ragged tile (image edge, or a cout tile past Cout): the same stores with the hardware range check doing the
+        // masking -- the channel row goes into the VGPR offset (the range check ignores the scalar offset), a lane
+        // without a pixel starts at 2^31, and everything at or past Cout * Hout * Wout * 4 bytes is dropped.
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)ybytes, 0x00020000);
+        const unsigned nb = (unsigned)ybytes;
+        if (rb) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] += rv[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned vo = pix[nt] >= 0 ? (unsigned)((4 * kh * HWo + pix[nt]) * 4) : 0x80000000u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned vr = vo + (unsigned)(((ct * TM + mt * 32 + (r & 3) + 8 * (r >> 2)) * HWo) * 4);
+                    const float v = acc[mt][nt][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)vr, 0, 0);
+                    am = max(am, vr < nb ? abs_bits(v) : 0u);
+                }
+        }
     } else
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1001,19 +1049,14 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
         }
         const int co = ct * TM + c;
         if (q == 0 && co < a.Cout) {
-            const int tile = blockIdx.x / a.cout_tiles, ntiles = a.tiles_x * a.tiles_y;
+            const int tile = sp_tile >= 0 ? sp_tile : (int)blockIdx.x / a.cout_tiles, ntiles = a.tiles_x * a.tiles_y;
             float* pp = a.stat_part + (((long)b * ntiles + tile) * a.Cout + co) * 2;
             pp[0] = mean; pp[1] = m2;
         }
     }
 }
 
-// RING: LDS stage buffers.  2: stage c+1 is written while stage c computes, one barrier per stage, and the first
-// fragment reads of a stage wait out their LDS latency behind the barrier.  3: stage c+2 is written while stage c
-// computes, so stage c+1 is already complete and PUBLISHED (by the previous barrier) -- its first fragments are read
-// during the last k-step of stage c, across the barrier, and the matrix pipe restarts without that bubble.  Same
-// accumulation order, same bits; the launcher picks 3 where two blocks per CU still fit the LDS.
-template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3, int RING = 2>
+template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // SPL = 3: three bf16 terms, six products.  SPL = 2: two fp16 terms of the operand scaled by a power of two
     // (activations x the sample's dynamic scale in the staging, weights per layer on the host), three products hh' + (hl' + lh'); the
@@ -1030,8 +1073,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     const int PP1 = PLANE + 1;                         // plane stride in units; unit PLANE = write sink
     const int xb_bytes = SPL * PP1 * 16;
     const int buf_bytes = xb_bytes + SLAB;
-    char* lds = smem;                                                  // RING x [Xb | Wb]
-    char* zunit = lds + RING * buf_bytes;                              // one all-zero 16-byte unit
+    char* lds = smem;                                                  // 2 x [Xb | Wb]
+    char* zunit = lds + 2 * buf_bytes;                              // one all-zero 16-byte unit
     float* ssl = reinterpret_cast<float*>(zunit + 16);                 // [Cin_pad][2]
     float* addv = ssl + a.Cin_pad * 2;                                 // [64] bias + per-sample add of this cout tile
     unsigned* wmax = reinterpret_cast<unsigned*>(addv + 64);           // [4] per-wave share of the activation bound
@@ -1048,13 +1091,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     const float* xb = a.x + (long)b * a.x_bs;
     const bool has_ss = a.ss != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
-#ifdef LNS_TS
-    long long ts_[6] = {0, 0, 0, 0, 0, 0};
-#define LNS_TSTAMP(i) { __builtin_amdgcn_sched_barrier(0); ts_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+    LNS_TS_DECL
     LNS_TSTAMP(0)
-#else
-#define LNS_TSTAMP(i)
-#endif
 
     // Prologue: everything the first stage needs is requested from global memory up front -- the row/column source
     // maps of this thread's patch units (direct loads, no LDS round trip), the GroupNorm scale/shift table and the
@@ -1131,11 +1169,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         for (int e = 0; e < 2; ++e) {
             const int c = c0 + 2 * cp + e;
             const float* cb = xb + (long)(c < a.Cin ? c : 0) * HWin;     // uniform
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 2048)               // 2048: every lane loads the same word (issue cost only)
-            pv[u][2 * cp + e] = __builtin_nontemporal_load(cb + (udm[u] & 0));
-#else
             pv[u][2 * cp + e] = cb[udm[u]];
-#endif
         }
     };
     // prologue transform + 3-way split of one channel pair
@@ -1159,9 +1193,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         constexpr int MODE = decltype(mode_tag)::value;
         float v0 = pv[u][2 * cp], v1 = pv[u][2 * cp + 1];
         if (MODE >= 1) { v0 = v0 * st.x + st.y; v1 = v1 * st.z + st.w; }
-#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 512))             // 512: no Swish in the loop's transform
         if (MODE == 2) { v0 = swish_fast(v0); v1 = swish_fast(v1); }
-#endif
         v0 *= uok[u]; v1 *= uok[u];
         if (SPL == 3) split3_pair(v0, v1, hq[u][cp], mq[u][cp], lq[u][cp]);
         else split2_pair_f16(v0, v1, hq[u][cp], mq[u][cp]);
@@ -1252,17 +1284,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         LNS_TSTAMP(2)
         int buf = 0;
         constexpr int MODE = decltype(mode_tag)::value;
-#if defined(LNS_KNOCK) && (LNS_KNOCK & (4096 | 8192))
-        float knock_v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) knock_v[q] = tid * 0.01f + q;
-#endif
         // (scale, shift) of channel pair 0 of stage 1, the first pair the loop transforms
         float4 stq = MODE >= 1 ? *reinterpret_cast<const float4*>(ssl + 2 * (KC < last ? KC : last)) : make_float4(1.f, 0.f, 1.f, 0.f);
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 32)             // 32: fragments read once, before the loop
-        uint4 af[2][SPL][MT], bf[2][SPL][NT];
-        load_frags(0, lds, lds + xb_bytes, af[0], bf[0]); load_frags(1, lds, lds + xb_bytes, af[1], bf[1]);
-#endif
         for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
             const char* Xs = lds + buf * buf_bytes;
             const char* Ws = Xs + xb_bytes;
@@ -1270,17 +1293,11 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             char* Wn = Xn + xb_bytes;
             const int cw = c0 + KC < last ? c0 + KC : last;
             const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 32)
-            (void)Xs; (void)Ws;
-#else
             uint4 af[2][SPL][MT], bf[2][SPL][NT];
             load_frags(0, Xs, Ws, af[0], bf[0]);
-#endif
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 32))
                 if (j + 1 < NJ) load_frags(j + 1, Xs, Ws, af[(j + 1) & 1], bf[(j + 1) & 1]);
-#endif
                 // this k-step transforms pair j of stage cw with the table entries read one k-step ago; the entries of
                 // the next pair to be transformed (pair j+1, or pair 0 of the following stage) are requested now
                 const float4 stu = stq;
@@ -1295,15 +1312,6 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                                          __builtin_bit_cast(bf16x8, Bq[SB][nt]), ACC[mt][nt], 0, 0, 0)                       \
                                    : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA][mt]),            \
                                          __builtin_bit_cast(f16x8, Bq[SB][nt]), ACC[mt][nt], 0, 0, 0);
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 1)          // timing what-if: no matrix instructions (fragments kept alive)
-#pragma unroll
-                for (int s_ = 0; s_ < SPL; ++s_) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) { f16x8 t_ = __builtin_bit_cast(f16x8, A[s_][mt]); asm volatile("" ::"v"(t_)); }
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) { f16x8 t_ = __builtin_bit_cast(f16x8, Bq[s_][nt]); asm volatile("" ::"v"(t_)); }
-                }
-#else
                 if (SPL == 3) {
                     LNS_BX3(acc_lo, 1, 1)
                     LNS_BX3(acc_hi, 0, 0)
@@ -1316,53 +1324,23 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                     LNS_BX3(acc_lo, 0, 1)
                     LNS_BX3(acc_lo, 1, 0)
                 }
-#endif
 #undef LNS_BX3
                 if (j < 4) {
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 2)          // no transform / split
-                        hq[u][j] = __float_as_uint(pv[u][2 * j]); mq[u][j] = __float_as_uint(pv[u][2 * j + 1]);
-#else
                         split_pair_r(mode_tag, u, j, stu);
-#endif
-#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 4))       // 4: no activation loads in the loop
                         load_pair(u, j, cl2);
-#endif
                     }
-#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 8))       // 8: no weight staging in the loop
 #pragma unroll
                     for (int i = 2 * j; i < 2 * j + 2; ++i)
                         if (i < NWU) {
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 256)        // 256: weight loads kept, their LDS writes dropped
-                            asm volatile("" ::"v"(wq[i][0]), "v"(wq[i][1]), "v"(wq[i][2]), "v"(wq[i][3]));
-#else
                             write_w(i, Wn);
-#endif
-#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 128))     // 128: weight LDS writes kept, their global loads dropped
                             load_w(i, cl2);
-#endif
                         }
-#endif
                 } else {
-#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 16))      // 16: no activation LDS writes (their operands kept alive)
 #pragma unroll
                     for (int u = 0; u < NU; ++u) flush_unit(u, Xn);
-#else
-#pragma unroll
-                    for (int u = 0; u < NU; ++u)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(hq[u][q]), "v"(mq[u][q]));
-#endif
                 }
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 4096)           // 4096: 20 synthetic independent FMAs per k-step (8 chains)
-#pragma unroll
-                for (int q = 0; q < 20; ++q) knock_v[q & 7] = __builtin_fmaf(knock_v[q & 7], 1.0001f, 0.5f);
-#endif
-#if defined(LNS_KNOCK) && (LNS_KNOCK & 8192)           // 8192: 20 synthetic FMAs per k-step in ONE dependent chain
-#pragma unroll
-                for (int q = 0; q < 20; ++q) knock_v[0] = __builtin_fmaf(knock_v[0], 1.0001f, 0.5f);
-#endif
                 // schedule: ALL LDS reads of the k-step first (next k-step's fragments + next pair's table entries:
                 // nothing in this k-step consumes them), then after each MFMA a few of the step's other instructions
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * SPL * (MT + NT) / 2 + 1, 0);
@@ -1375,131 +1353,13 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 64))          // 64: no stage barrier
             __syncthreads();
-#endif
             buf ^= 1;
         }
-#if defined(LNS_KNOCK) && (LNS_KNOCK & (4096 | 8192))
-#pragma unroll
-        for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(knock_v[q]));
-#endif
     };
-    // The same loop on a ring of three stage buffers (see the template comment).
-    auto k_loop3 = [&](auto mode_tag) __attribute__((always_inline)) {
-        const int last = a.Cin_pad - KC;
-        auto clampc = [&](int c) { return c < last ? c : last; };
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int cp = 0; cp < 4; ++cp) load_pair(u, cp, 0);
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) load_w(i, 0);
-        {
-            float addreg = 0.0f;
-            if (tid < TM) {
-                const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
-                addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
-            }
-            stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
-            if (tid < TM) addv[tid] = addreg;
-        }
-        __syncthreads();                                   // ssl / addv / wmax / zunit visible
-        if (SPL == 2) {
-            const float xs = f16x2_scale(block_bound(a, wmax), xinv);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) uok[u] *= xs;
-        }
-        // stages 0 and 1 into ring slots 0 and 1, stage 2 raw into registers
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int cs = clampc(st * KC), cn = clampc((st + 1) * KC);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-#pragma unroll
-                for (int cp = 0; cp < 4; ++cp) { split_pair(mode_tag, u, cp, cs); load_pair(u, cp, cn); }
-                flush_unit(u, lds + st * buf_bytes);
-            }
-#pragma unroll
-            for (int i = 0; i < NWU; ++i) { write_w(i, lds + st * buf_bytes + xb_bytes); load_w(i, cn); }
-        }
-        __syncthreads();
-        uint4 af[2][SPL][MT], bf[2][SPL][NT];              // fragment slots live across stages (cross-barrier prefetch)
-        load_frags(0, lds, lds + xb_bytes, af[0], bf[0]);
-        int b0 = 0;
-        auto stage = [&](auto parity_tag, int c0) __attribute__((always_inline)) {
-            constexpr int P = decltype(parity_tag)::value;
-            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-            const char* Xs = lds + b0 * buf_bytes;
-            const char* Ws = Xs + xb_bytes;
-            const char* Xnx = lds + b1 * buf_bytes;        // next stage: complete and published by the previous barrier
-            char* Xw = lds + b2 * buf_bytes;               // stage c+2: written now
-            char* Ww = Xw + xb_bytes;
-            const int cw = clampc(c0 + 2 * KC), cl3 = clampc(c0 + 3 * KC);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (j + 1 < NJ) load_frags(j + 1, Xs, Ws, af[(j + 1 + P) & 1], bf[(j + 1 + P) & 1]);
-                else load_frags(0, Xnx, Xnx + xb_bytes, af[(NJ + P) & 1], bf[(NJ + P) & 1]);     // next stage's k-step 0
-                auto& A = af[(j + P) & 1];
-                auto& Bq = bf[(j + P) & 1];
-#define LNS_BX3(ACC, SA, SB)                                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
-            ACC[mt][nt] = SPL == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA][mt]),          \
-                                         __builtin_bit_cast(bf16x8, Bq[SB][nt]), ACC[mt][nt], 0, 0, 0)                       \
-                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA][mt]),            \
-                                         __builtin_bit_cast(f16x8, Bq[SB][nt]), ACC[mt][nt], 0, 0, 0);
-                if (SPL == 3) {
-                    LNS_BX3(acc_lo, 1, 1)
-                    LNS_BX3(acc_hi, 0, 0)
-                    LNS_BX3(acc_lo, 0, SPL - 1)
-                    LNS_BX3(acc_lo, SPL - 1, 0)
-                    LNS_BX3(acc_lo, 0, 1)
-                    LNS_BX3(acc_lo, 1, 0)
-                } else {
-                    LNS_BX3(acc_hi, 0, 0)
-                    LNS_BX3(acc_lo, 0, 1)
-                    LNS_BX3(acc_lo, 1, 0)
-                }
-#undef LNS_BX3
-                if (j < 4) {
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) { split_pair(mode_tag, u, j, cw); load_pair(u, j, cl3); }
-#pragma unroll
-                    for (int i = 2 * j; i < 2 * j + 2; ++i)
-                        if (i < NWU) { write_w(i, Ww); load_w(i, cl3); }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) flush_unit(u, Xw);
-                }
-#pragma unroll
-                for (int g = 0; g < (SPL == 3 ? 6 : 3) * MT * NT; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, SPL == 3 ? 1 : 2, 0);   // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, SPL == 3 ? 5 : 8, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-            b0 = b1;
-        };
-        for (int c0 = 0; c0 < a.Cin_pad; c0 += 2 * KC) {       // NJ is odd: the fragment slot parity alternates per stage
-            stage(std::integral_constant<int, 0>{}, c0);
-            if (c0 + KC < a.Cin_pad) stage(std::integral_constant<int, 1>{}, c0 + KC);
-        }
-    };
-    if constexpr (RING == 3) {
-        static_assert(NJ % 2 == 1, "slot parity scheme assumes an odd number of k-steps per stage");
-        if (pro_mode == 2) k_loop3(std::integral_constant<int, 2>{});
-        else if (pro_mode == 1) k_loop3(std::integral_constant<int, 1>{});
-        else k_loop3(std::integral_constant<int, 0>{});
-    } else {
-        if (pro_mode == 2) k_loop(std::integral_constant<int, 2>{});
-        else if (pro_mode == 1) k_loop(std::integral_constant<int, 1>{});
-        else k_loop(std::integral_constant<int, 0>{});
-    }
+    if (pro_mode == 2) k_loop(std::integral_constant<int, 2>{});
+    else if (pro_mode == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
 
     // ---- epilogue (fp32) ---------------------------------------------------------
     int pix[NT];
@@ -1515,18 +1375,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                                   (a.bias || a.badd) ? addv : nullptr);
     LNS_TSTAMP(4)
     if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);    // wmax: free since the prologue
-#ifdef LNS_TS
-    __builtin_amdgcn_s_waitcnt(0);                       // stores acknowledged
-    LNS_TSTAMP(5)
-    if (a.dbg_ts && tid == 0) {
-        long long* d = a.dbg_ts + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = ts_[i];
-        d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
-        d[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
-    }
-#endif
-#undef LNS_TSTAMP
+    LNS_TS_DUMP
 }
 
 // ===========================================================================
@@ -1563,6 +1412,8 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
     const float* xb = a.x + (long)b * a.x_bs;
     const bool has_ss = a.ss != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
+    LNS_TS_DECL
+    LNS_TSTAMP(0)
 
     // (ssl / addv / the activation bound are staged in k_loop behind the first stage's global loads, and the barrier
     //  that publishes them comes after: one memory latency before the first split instead of two)
@@ -1669,6 +1520,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
             if (tid < TM) addv[tid] = addreg;
         }
         __syncthreads();                                   // ssl / addv / wmax visible
+        LNS_TSTAMP(1)
         if (SPL == 2) {
             const float xs = f16x2_scale(block_bound(a, wmax), xinv);
 #pragma unroll
@@ -1690,6 +1542,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
             for (int i = 0; i < NWU; ++i) load_w(i, c1);
         }
         __syncthreads();
+        LNS_TSTAMP(2)
         int buf = 0;
         for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
             const char* Xs = lds + buf * BUF;
@@ -1762,8 +1615,11 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
         pix[0] = p < a.Hout * a.Wout ? p : -1;
     }
     unsigned am = 0u;
+    LNS_TSTAMP(3)
     convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am, (a.bias || a.badd) ? addv : nullptr);
+    LNS_TSTAMP(4)
     if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);
+    LNS_TS_DUMP
 }
 
 // Input-stationary form of the 1x1 kernel for narrow inputs (Cin_pad <= 64) feeding many output channels:
@@ -1792,6 +1648,8 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
     const int p0 = tx * TN;
     const float* xb = a.x + (long)b * a.x_bs;
     const bool has_ss = a.ss != nullptr;
+    LNS_TS_DECL
+    LNS_TSTAMP(0)
 
     float xinv = 1.0f;
 
@@ -1826,6 +1684,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
             if (st == 0) {
                 stage_ss_bound(a, b, ssl, wmax, tid, NTHR);  // behind the first stage's global loads
                 __syncthreads();                            // ssl / wmax visible
+                LNS_TSTAMP(1)
                 if (SPL == 2) {
                     const float xs = f16x2_scale(block_bound(a, wmax), xinv);
 #pragma unroll
@@ -1880,6 +1739,7 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NWU; ++i) load_w(i, 1);
     __syncthreads();
+    LNS_TSTAMP(2)
 
     f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
     int pix[NT];
@@ -1954,7 +1814,10 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
             ++ctl;
         }
     }
+    LNS_TSTAMP(3)
+    LNS_TSTAMP(4)
     if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);    // once per block, over all its cout tiles
+    LNS_TS_DUMP
 }
 
 size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 64 * 4 + 16 + 16; }
@@ -2162,21 +2025,6 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     if (variant == CV_F64) {                              // two-term fp16 split
-        // ring of three stage buffers (opt-in, LNS_CONV3_RING=3; where two blocks per CU still fit the LDS).  Measured on
-        // NS2d-128 B=64: 3x3 class 87.5 vs 86.4 ms serial, rollout 153.9 vs 150.3 ms -- the co-resident wave already
-        // covers the stage-start fragment latency and the longer prologue costs more than the bubble: default 2.
-        static const int ring_env = getenv("LNS_CONV3_RING") ? atoi(getenv("LNS_CONV3_RING")) : 2;
-        const size_t lds3 = convb_lds_bytes(a, 64, 2, 3);
-        if (ring_env == 3 && 2 * (lds3 + 512) <= 160 * 1024) {
-            if (a.w2) {
-                if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true, 2, 2, 3>), grid, dim3(256), lds3, s, a);
-                else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true, 2, 2, 3>), grid, dim3(256), lds3, s, a);
-            } else {
-                if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 2, 2, 3>), grid, dim3(256), lds3, s, a);
-                else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 2, 2, 3>), grid, dim3(256), lds3, s, a);
-            }
-            return hipGetLastError();
-        }
         const size_t lds = convb_lds_bytes(a, 64, 2, 2);
         if (a.w2) {
             if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true, 2, 2>), grid, dim3(256), lds, s, a);
@@ -4045,10 +3893,6 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv1_bf16x3_kernel<true, false>))
     LNS_SET_LDS((conv1_bf16x3_kernel<false, true>))
     LNS_SET_LDS((conv1_bf16x3_kernel<false, false>))
-    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 2, 2, 3>))
-    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2, 3>))
-    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true, 2, 2, 3>))
-    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true, 2, 2, 3>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<2, 2, false, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<2, 2, true, 2, 2>))

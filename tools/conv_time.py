@@ -21,6 +21,13 @@ cases = {
     "flat": dict(B=64, Cin=8, Cout=128, H=16, W=16, k=3, ss=True, act=0),
     "flat_16": dict(B=64, Cin=16, Cout=128, H=16, W=16, k=3, ss=True, act=0),
     "f1blk": dict(B=1, Cin=8, Cout=64, H=16, W=8, k=3, ss=True, act=1),            # a single block
+    "k1_lat": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=1, ss=True, act=0),
+    "k1_lat_up": dict(B=64, Cin=128, Cout=512, H=16, W=16, k=1, ss=True, act=0),
+    "k1_lat_dn": dict(B=64, Cin=512, Cout=128, H=16, W=16, k=1, ss=True, act=0),
+    "k1_inproj": dict(B=64, Cin=64, Cout=512, H=64, W=64, k=1, ss=True, act=0, v=8),    # input-stationary form
+    "k1_toout": dict(B=64, Cin=512, Cout=64, H=64, W=64, k=1, ss=True, act=0),
+    "k1_128": dict(B=64, Cin=64, Cout=64, H=128, W=128, k=1, ss=True, act=1),
+    "lat_d4": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0, dil=4),
     "lat_b256": dict(B=256, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0),
 }
 NREP = 5
@@ -58,11 +65,12 @@ for name in which:
     w = (np.random.RandomState(0).randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = np.zeros(Cout, np.float32)
     ss = torch.stack([1 + 0.1 * torch.randn(B, Cin), 0.1 * torch.randn(B, Cin)], -1).cuda().contiguous()
-    p = (k - 1) // 2
+    dil = c.get("dil", 1)
+    p = dil * (k - 1) // 2
     y = torch.empty(B, Cout, Hv, Wv, device="cuda")
     def run():
-        rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, Hv, Wv, gc._hp(w), gc._hp(bias), Cout, k, 1, 1, p, p, p, p, 1, 1,
-                             ss.data_ptr(), c["act"], 0, None, None, y.data_ptr(), VARIANT if k == 3 else -1, None, None)
+        rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, Hv, Wv, gc._hp(w), gc._hp(bias), Cout, k, 1, dil, p, p, p, p, 1, 1,
+                             ss.data_ptr(), c["act"], 0, None, None, y.data_ptr(), c.get("v", VARIANT if k == 3 else 7), None, None)
         assert rc == 0
     for _ in range(NREP):
         run()

@@ -21,6 +21,7 @@ seen = {}
 for hdr, a in launches:
     seen[hdr] = a                      # last launch of each shape (warm)
 for hdr, a in seen.items():
+    a = a[a[:, 1] != 0]                 # rows of blocks that do not exist in this launch form
     ts = a[:, 1:7].astype(np.float64) / 100.0          # us
     hw, xcc = a[:, 7], a[:, 8]
     cu = ((xcc & 0xF) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)

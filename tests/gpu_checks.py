@@ -31,7 +31,7 @@ def rng(seed):
 
 def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), up=None, ss=False, act_in=0,
               act_out=0, res=False, badd=False, bias=True, variant=-1, seed=0, xscale=1.0, sample_scales=None,
-              heavy_w=False, xdist="normal", fp64=False):
+              heavy_w=False, xdist="normal", fp64=False, ret_y=False):
     """Returns (rel_l2 error, output shape) of lns_op_conv2d vs the oracle composition.
     xscale / sample_scales: magnitude of the activations (per sample); heavy_w: heavy-tailed (Student-t, 2 dof)
     weights; xdist "lognormal": activations spread over several decades; fp64: additionally returns the error
@@ -103,6 +103,8 @@ def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), u
         assert np.array_equal(got, want), ("amax side channel", got, want)
     # every sample on its own (samples of one batch may differ by orders of magnitude)
     err = max(rel_l2(out[i], ref[i]) for i in range(B))
+    if ret_y:
+        return err, ref.shape, out
     if fp64:
         r64 = conv_case_fp64(x, w, bv, stride, dil, pad, mode, up, ssv, act_in, badd_v, act_out, res_v)
         return err, ref.shape, max(rel_l2(out[i], r64[i]) for i in range(B))
@@ -180,6 +182,7 @@ for _c in [dict(B=2, Cin=64, Cout=64, H=32, W=32, mode=(1, 1)), dict(B=2, Cin=64
     if not (_c.get('Cout') == 64 and _c.get('Cin') == 512):
         CONV_CASES.append(dict(k=3, variant=9, **_c))     # 32-cout tiles of the same kernel
         CONV_CASES.append(dict(k=3, variant=13, **_c))    # f16x2 with 32-cout tiles
+        CONV_CASES.append(dict(k=3, variant=14, **_c))    # f16x2 with 256-pixel tiles (a wave owns 64 couts x 64 pixels)
 # bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel
 # counts, prologue and epilogue features
 for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, Cout=128, H=16, W=16),

@@ -46,6 +46,19 @@ def test_conv_kernel(idx, case):
     assert err < KERNEL_TOL, (case, err)
 
 
+def test_conv_tile_variants_same_bits():
+    """The f16x2 3x3 kernel accumulates every output element in the same order whatever the block tile: 64 couts x 128
+    pixels (11), 32 x 128 (13) and 64 x 256 (14) agree bit for bit -- full tiles, ragged edges and a ragged cout tile."""
+    _need_gpu()
+    import gpu_checks as gc
+    import numpy as np
+    for kw in (dict(B=2, Cin=64, Cout=64, H=32, W=32, ss=True, act_in=1, res=True),
+               dict(B=2, Cin=40, Cout=100, H=21, W=37, ss=True, act_in=1, badd=True, mode=(0, 0)),
+               dict(B=2, Cin=64, Cout=128, H=28, W=60, up=(61, 121), mode=(0, 0))):
+        ys = [gc.conv_case(k=3, variant=v, seed=5, ret_y=True, **kw)[2] for v in (11, 13, 14)]
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2]), kw
+
+
 def _domain_cases():
     import gpu_checks as gc
     return list(enumerate(gc.DOMAIN_CASES))

@@ -580,9 +580,9 @@ struct Planner {
         const int C = x.C, H = x.H, W = x.W, heads = l.heads, dh = l.dim_head, lat = l.fa_lat, DK = l.fa_dk;
         TRef xin = x; xin.owned = false;
         emit_gn(xin, 1, 1e-5f, l.fa_g, l.fa_b, 0, l.name + ".in_norm");
-        // (no amax for these two: their consumers -- sandwich on bf16x3, pooling -- need none, and the 512-plane
-        //  tensor is the largest of the path)
-        TRef uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj", -1, false);
+        // in_proj records max |u| per sample: the sandwich's f16x2 form scales its planes by it (to_in's consumer, the
+        // pooling, needs none)
+        TRef uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj", -1, true);
         TRef v = conv_same1(xin, l.toin, ACT_NONE, nullptr, nullptr, l.name + ".to_in", -1, false);
         free_t(xin);
         // axis pooling
@@ -669,6 +669,7 @@ struct Planner {
             op.fs.u = as_ptr<const float>(uphi.ptr); op.fs.kx = as_ptr<const float>(tag(SP_WS, kx_off));
             op.fs.ky = as_ptr<const float>(tag(SP_WS, ky_off)); op.fs.B = B; op.fs.heads = heads; op.fs.C = dh;
             op.fs.H = H; op.fs.W = W; op.fs.eps = 1e-5f; op.fs.instnorm = 1; op.fs.out = as_ptr<float>(uphi.ptr);
+            op.fs.amax_u = uphi.amax ? as_ptr<const unsigned>(uphi.amax) : nullptr;
             op.flops = 2.0 * B * heads * dh * ((double)H * W * W + (double)H * H * W);
             op.bytes = 8.0 * B * heads * dh * H * W;
             plan->ops.push_back(op);
@@ -1236,7 +1237,7 @@ struct Runner {
                 }
                 case OP_FASAND: {
                     FaSandwichArgs a = op.fs;
-                    fix(a.u, B); fix(a.kx, B); fix(a.ky, B); fix(a.out, B);
+                    fix(a.u, B); fix(a.kx, B); fix(a.ky, B); fix(a.out, B); fix(a.amax_u, B);
                     rc = launch_fa_sandwich(a, stream);
                     break;
                 }
@@ -2098,10 +2099,17 @@ int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, 
                        int apply_instance_norm, float* out, void* stream) {
     if (!u || !kx || !ky || !out) return LNS_EINVAL;
     OPCHK(init_kernels());
-    FaSandwichArgs a = {u, kx, ky, B, heads, C, H, W, eps, apply_instance_norm, out};
+    FaSandwichArgs a = {u, kx, ky, B, heads, C, H, W, eps, apply_instance_norm, out, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    OPCHK(launch_fa_sandwich(a, s));
-    OPCHK(hipStreamSynchronize(s));
+    // max |u| per sample (what the in_proj convolution records inside a plan): enables the f16x2 form
+    unsigned* damax = nullptr;
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&damax), (size_t)B * LNS_AMAX_SUB * 4));
+    hipError_t he = hipMemsetAsync(damax, 0, (size_t)B * LNS_AMAX_SUB * 4, s);
+    if (he == hipSuccess) he = launch_amax(u, (long)heads * C * H * W, (long)heads * C * H * W, B, damax, s);
+    if (he == hipSuccess) { a.amax_u = damax; he = launch_fa_sandwich(a, s); }
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    (void)hipFree(damax);
+    OPCHK(he);
     return LNS_OK;
 }
 

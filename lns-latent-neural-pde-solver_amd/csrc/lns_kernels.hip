@@ -3403,6 +3403,308 @@ __global__ __launch_bounds__(64 * NWV, 1) void fa_sandwich_b_kernel(FaSandwichAr
     }
 }
 
+// ---------------------------------------------------------------------------
+// The sandwich on the two-term fp16 split (f16x2, the scheme of the convolution kernels): three products per fp32
+// product instead of six, two split terms instead of three, 2/3 of the LDS image -- so TWO blocks fit a CU (74 KB at
+// 64 x 64) where the bf16x3 form fits one.  Every operand is multiplied by a power of two that puts its bound at
+// 2^14 <= . < 2^15 before the split:
+//   P  : the sample's max |u| (amax side channel of the in_proj convolution, FaSandwichArgs::amax_u)
+//   Kx, Ky : their own maxima over the (sample, head) matrix, reduced in the block prologue
+//   U = P Ky^T : |U[j][l]| <= max|P| * max_l sum_m |Ky[l][m]| (largest absolute row sum of Ky, prologue as well) --
+//        ONE scale for all bands of a plane, because the bands accumulate into the same Y accumulators
+// All four are functions of the sample alone, never of the batch.  Two blocks per CU for W <= 64; the 48 x 96 planes of
+// the SW decoder (WT = 3, 111 KB) run one block per CU with the whole register file.
+// ---------------------------------------------------------------------------
+template <int HT, int WT, bool VEC, bool FULL, bool ULOOP>
+__global__ __launch_bounds__(256, (WT <= 2 ? 2 : 1)) void fa_sandwich_f_kernel(FaSandwichArgs a, int planes_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPL = 2, NWV = 4;
+    constexpr int HB = HT * 32, WB = WT * 32, NTHR = 64 * NWV;
+    constexpr int KXW = HB + 8, KYW = WB + 8;               // row strides in fp16 elements
+    constexpr int NPH = 32 * WB / 64;                       // plane floats per lane per 32-row band
+    constexpr int NQH = VEC ? NPH / 4 : NPH;
+    unsigned short* Kxs = reinterpret_cast<unsigned short*>(smem);      // [2][HB][KXW]
+    unsigned short* Kys = Kxs + SPL * HB * KXW;                         // [2][WB][KYW]
+    unsigned short* Pall = Kys + SPL * WB * KYW;                        // 4 x [2][32][KYW]
+    unsigned* red = reinterpret_cast<unsigned*>(Pall + NWV * SPL * 32 * KYW);   // [4 waves][3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int H = a.H, W = a.W, C = a.C;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
+    const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
+    float s_p, i_p, s_kx, i_kx, s_ky, i_ky, s_u, i_u;       // scales and their inverses (powers of two)
+    {   // Kx (column-permuted) and Ky: all loads of a thread in flight at once, then the block-wide bounds, then the split
+        constexpr int NX = (HB * HB + NTHR - 1) / NTHR, NY = (WB * WB + NTHR - 1) / NTHR;
+        // threads per Ky row (a power of two, so that a row's threads are neighbouring lanes) and elements per thread
+        constexpr int TPR = NTHR / WB >= 8 ? 8 : (NTHR / WB >= 4 ? 4 : 2), EPT = (WB + TPR - 1) / TPR;
+        float vx[NX], vy[NY], rsv[EPT];
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * NTHR, r = i / HB, c = i - r * HB;
+            vx[u] = (r < H && c < H) ? kxg[(long)r * H + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * NTHR, r = i / WB, c = i - r * WB;
+            vy[u] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
+        }
+        {
+            const int r = tid / TPR, q = tid - r * TPR;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int c = q * EPT + e;
+                rsv[e] = (r < W && c < W) ? kyg[(long)r * W + c] : 0.0f;
+            }
+        }
+        unsigned mx = 0u, my = 0u;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) mx = max(mx, abs_bits(vx[u]));
+#pragma unroll
+        for (int u = 0; u < NY; ++u) my = max(my, abs_bits(vy[u]));
+        float rs = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) rs += fabsf(rsv[e]);
+#pragma unroll
+        for (int d = 1; d < TPR; d <<= 1) rs += __shfl_xor(rs, d);        // fixed order: the same sum on every lane of the row
+        mx = wave_umax(mx); my = wave_umax(my);
+        const unsigned mr = wave_umax(__float_as_uint(rs));
+        if (lane == 0) { red[wave * 3] = mx; red[wave * 3 + 1] = my; red[wave * 3 + 2] = mr; }
+        __syncthreads();
+        const unsigned bx = max(max(red[0], red[3]), max(red[6], red[9]));
+        const unsigned by = max(max(red[1], red[4]), max(red[7], red[10]));
+        const unsigned br = max(max(red[2], red[5]), max(red[8], red[11]));
+        const unsigned bp = amax_load(a.amax_u, b);
+        s_kx = f16x2_scale(bx, i_kx);
+        s_ky = f16x2_scale(by, i_ky);
+        s_p = f16x2_scale(bp, i_p);
+        s_u = f16x2_scale(__float_as_uint(__uint_as_float(bp) * __uint_as_float(br)), i_u);
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * NTHR, r = i / HB, c = i - r * HB;
+            if (i >= HB * HB) continue;
+            const int w = c & 15;
+            const int cp = (c & ~15) | (w & 3) | (((w >> 3) & 1) << 2) | (((w >> 2) & 1) << 3);
+            const float v = vx[u] * s_kx;
+            const _Float16 hh = (_Float16)v, ll = (_Float16)(v - (float)hh);
+            Kxs[(0 * HB + r) * KXW + cp] = __builtin_bit_cast(unsigned short, hh);
+            Kxs[(1 * HB + r) * KXW + cp] = __builtin_bit_cast(unsigned short, ll);
+        }
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * NTHR, r = i / WB, c = i - r * WB;
+            if (i >= WB * WB) continue;
+            const float v = vy[u] * s_ky;
+            const _Float16 hh = (_Float16)v, ll = (_Float16)(v - (float)hh);
+            Kys[(0 * WB + r) * KYW + c] = __builtin_bit_cast(unsigned short, hh);
+            Kys[(1 * WB + r) * KYW + c] = __builtin_bit_cast(unsigned short, ll);
+        }
+    }
+    unsigned short* Ps = Pall + wave * (SPL * 32 * KYW);
+    for (int i = lane; i < SPL * 32 * KYW / 2; i += 64) reinterpret_cast<unsigned*>(Ps)[i] = 0u;   // K padding stays zero
+    __syncthreads();
+
+    int soff[NQH], doff[NQH];
+    {
+        const int per_row = VEC ? W / 4 : W;
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int f = lane + 64 * q;
+            const int r = f / per_row, c = (f - r * per_row) * (VEC ? 4 : 1);
+            soff[q] = r < 32 ? r * W + c : -1;
+            doff[q] = r * KYW + c;
+        }
+    }
+    float pf[NPH];
+    auto prefetch = [&](const float* pg, int jt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const bool ok = FULL || (soff[q] >= 0 && (jt * 32 + soff[q] / W) < H);
+            const int so = ok ? jt * 32 * W + soff[q] : 0;
+            if (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(pg + so);
+                pf[4 * q] = t.x; pf[4 * q + 1] = t.y; pf[4 * q + 2] = t.z; pf[4 * q + 3] = t.w;
+            } else {
+                pf[q] = pg[so];
+            }
+        }
+    };
+
+    const int c_begin = blockIdx.x * planes_per_block;
+    const float inv_cnt = 1.0f / (float)(H * W);
+    const long plane0 = ((long)b * a.heads + h) * C;
+    int c = c_begin + wave;
+    const int c_end = min(c_begin + planes_per_block, C);
+    if (c < c_end) prefetch(a.u + (plane0 + c) * H * W, 0);
+    const char* pa = reinterpret_cast<const char*>(Ps) + (l31 * KYW + 8 * kh) * 2;                  // + s*32*KYW*2 + t*32
+    const char* kyb = reinterpret_cast<const char*>(Kys) + (l31 * KYW + 8 * kh) * 2;                // + (s*WB + lt*32)*KYW*2 + t*32
+    const char* kxa = reinterpret_cast<const char*>(Kxs) + (l31 * KXW + 8 * kh) * 2;                // + (s*HB + it*32)*KXW*2 + (jt*32+16t')*2
+    for (; c < c_end; c += NWV) {
+        // one accumulator per tile for all three products (hh' + hl' + lh'): the cross terms are 2^-11 of the main one,
+        // adding them into the same fp32 accumulator costs what any fp32 chain costs -- and halves the registers, which
+        // is what lets two waves share a SIMD
+        f32x16 Yh[HT][WT];
+#pragma unroll
+        for (int i = 0; i < HT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Yh[i][j][r] = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt) {
+            // band jt: registers -> scale, split -> this wave's private LDS band.  LDS operations of one wave execute in order.
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const bool ok = FULL || (soff[q] >= 0 && (jt * 32 + soff[q] / W) < H);
+                if (FULL || soff[q] >= 0) {
+                    if (VEC) {
+                        unsigned h0, l0, h1, l1;
+                        split2_pair_f16(ok ? pf[4 * q] * s_p : 0.0f, ok ? pf[4 * q + 1] * s_p : 0.0f, h0, l0);
+                        split2_pair_f16(ok ? pf[4 * q + 2] * s_p : 0.0f, ok ? pf[4 * q + 3] * s_p : 0.0f, h1, l1);
+                        *reinterpret_cast<uint2*>(Ps + 0 * 32 * KYW + doff[q]) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(Ps + 1 * 32 * KYW + doff[q]) = make_uint2(l0, l1);
+                    } else {
+                        const float v = ok ? pf[q] * s_p : 0.0f;
+                        const _Float16 hh = (_Float16)v, ll = (_Float16)(v - (float)hh);
+                        Ps[0 * 32 * KYW + doff[q]] = __builtin_bit_cast(unsigned short, hh);
+                        Ps[1 * 32 * KYW + doff[q]] = __builtin_bit_cast(unsigned short, ll);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (jt + 1 < HT) prefetch(a.u + (plane0 + c) * H * W, jt + 1);
+            else if (c + NWV < c_end) prefetch(a.u + (plane0 + c + NWV) * H * W, 0);
+            constexpr int UT = ULOOP ? 1 : WT;
+#pragma unroll
+            for (int l0 = 0; l0 < WT; l0 += UT) {
+                // U[j][l] = sum_m P[j][m] Ky[l][m]
+                f32x16 Uh[UT];
+#pragma unroll
+                for (int lt = 0; lt < UT; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Uh[lt][r] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < WB / 16; ++t) {
+                    f16x8 A[SPL], Bq[UT][SPL];
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s) {
+                        A[s] = *reinterpret_cast<const f16x8*>(pa + s * (32 * KYW * 2) + t * 32);
+#pragma unroll
+                        for (int lt = 0; lt < UT; ++lt)
+                            Bq[lt][s] = *reinterpret_cast<const f16x8*>(kyb + (s * WB + (l0 + lt) * 32) * (KYW * 2) + t * 32);
+                    }
+#pragma unroll
+                    for (int lt = 0; lt < UT; ++lt) Uh[lt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], Bq[lt][0], Uh[lt], 0, 0, 0);
+#pragma unroll
+                    for (int lt = 0; lt < UT; ++lt) Uh[lt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], Bq[lt][1], Uh[lt], 0, 0, 0);
+#pragma unroll
+                    for (int lt = 0; lt < UT; ++lt) Uh[lt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], Bq[lt][0], Uh[lt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);       // one k-step of fragments in registers at a time (register budget of two waves per SIMD)
+                }
+#pragma unroll
+                for (int ul = 0; ul < UT; ++ul) {
+                    const int lt = l0 + ul;
+                    // U back to its true scale, then to the scale of its bound; split in registers: k-step t' of the
+                    // second product takes registers 8t'..8t'+7
+                    uint4 Bu[2][SPL];
+#pragma unroll
+                    for (int tp = 0; tp < 2; ++tp) {
+                        unsigned hq[4], lq[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float u0 = ((Uh[ul][8 * tp + 2 * e] * i_p) * i_ky) * s_u;
+                            const float u1 = ((Uh[ul][8 * tp + 2 * e + 1] * i_p) * i_ky) * s_u;
+                            split2_pair_f16(u0, u1, hq[e], lq[e]);
+                        }
+                        Bu[tp][0] = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+                        Bu[tp][1] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+                    }
+                    // Y[i][l] += sum_{j in band} Kx[i][j] U[j][l]
+#pragma unroll
+                    for (int tp = 0; tp < 2; ++tp) {
+                        f16x8 A[HT][SPL], Bq[SPL];
+#pragma unroll
+                        for (int s = 0; s < SPL; ++s) {
+#pragma unroll
+                            for (int it = 0; it < HT; ++it)
+                                A[it][s] = *reinterpret_cast<const f16x8*>(kxa + (s * HB + it * 32) * (KXW * 2) + (jt * 32 + 16 * tp) * 2);
+                            Bq[s] = __builtin_bit_cast(f16x8, Bu[tp][s]);
+                        }
+#pragma unroll
+                        for (int it = 0; it < HT; ++it) Yh[it][lt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[it][0], Bq[0], Yh[it][lt], 0, 0, 0);
+#pragma unroll
+                        for (int it = 0; it < HT; ++it) Yh[it][lt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[it][0], Bq[1], Yh[it][lt], 0, 0, 0);
+#pragma unroll
+                        for (int it = 0; it < HT; ++it) Yh[it][lt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[it][1], Bq[0], Yh[it][lt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }   // l0
+        }
+#pragma unroll
+        for (int it = 0; it < HT; ++it)
+#pragma unroll
+            for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Yh[it][lt][r] = (Yh[it][lt][r] * i_kx) * i_u;
+        float mean = 0.0f, rstd = 1.0f;
+        if (a.instnorm) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int it = 0; it < HT; ++it)
+#pragma unroll
+                for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool v = FULL || ((it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W));
+                        sacc += v ? Yh[it][lt][r] : 0.0f;
+                    }
+            mean = wave_sum(sacc) * inv_cnt;
+            float q = 0.0f;
+#pragma unroll
+            for (int it = 0; it < HT; ++it)
+#pragma unroll
+                for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool v = FULL || ((it * 32 + drow(r, kh) < H) && (lt * 32 + l31 < W));
+                        const float d = Yh[it][lt][r] - mean;
+                        q += v ? d * d : 0.0f;
+                    }
+            rstd = 1.0f / sqrtf(wave_sum(q) * inv_cnt + a.eps);
+        }
+        // stores through a buffer descriptor of the plane (its base made provably wave-uniform): the lane's offset in one
+        // VGPR, the row offset in an SGPR -- per-element 64-bit addresses would cost 128 registers here
+        float* og = a.out + (plane0 + c) * H * W;
+        const unsigned long long ogp = reinterpret_cast<unsigned long long>(og);
+        const unsigned og_lo = __builtin_amdgcn_readfirstlane((unsigned)ogp), og_hi = __builtin_amdgcn_readfirstlane((unsigned)(ogp >> 32));
+        const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((unsigned long long)og_hi << 32) | og_lo), 0, H * W * 4, 0x00020000);
+        const int vo = (4 * kh * W + l31) * 4;
+#pragma unroll
+        for (int it = 0; it < HT; ++it)
+#pragma unroll
+            for (int lt = 0; lt < WT; ++lt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int so = ((it * 32 + (r & 3) + 8 * (r >> 2)) * W + lt * 32) * 4;      // uniform
+                    const float v = (Yh[it][lt][r] - mean) * rstd;
+                    if (FULL) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, vo, so, 0);
+                    } else {        // ragged plane: the range check masks (the row offset in the VGPR, invalid lanes at 2^31)
+                        const int i = it * 32 + drow(r, kh), l = lt * 32 + l31;
+                        const unsigned vr = (i < H && l < W) ? (unsigned)(vo + so) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, (int)vr, 0, 0);
+                    }
+                }
+    }
+}
+static size_t fa_sandwich_f_lds_bytes(int HT, int WT) {
+    const size_t HB = HT * 32, WB = WT * 32;
+    return (2 * HB * (HB + 8) + 2 * WB * (WB + 8) + (size_t)4 * 2 * 32 * (WB + 8)) * 2 + 64;
+}
+
 constexpr size_t fa_sandwich_b_lds_const(int HT, int WT, int nwv) {
     return ((size_t)3 * HT * 32 * (HT * 32 + 8) + (size_t)3 * WT * 32 * (WT * 32 + 8) + (size_t)nwv * 3 * 32 * (WT * 32 + 8)) * 2;
 }
@@ -3428,6 +3730,24 @@ static hipError_t launch_fa_sandwich_t(const FaSandwichArgs& a, hipStream_t s) {
     static const bool three_wave = getenv("LNS_FA_SANDWICH_3WAVE") != nullptr;
     constexpr int NWV = fa_sandwich_b_lds_const(HT, WT, 4) <= 160 * 1024 ? 4 : 3;
     constexpr bool UL = HT * WT >= 6;
+    // f16x2 form: planes of <= 96 columns whose producer recorded max |u| per sample (a per-layer condition)
+    static const bool no_f16 = getenv("LNS_FA_SANDWICH_BF16X3") != nullptr;
+    if constexpr (WT <= 3) {
+        if (!fp32_only && !no_f16 && a.amax_u != nullptr && fa_sandwich_f_lds_bytes(HT, WT) <= 160 * 1024) {
+            static const int ppb_max = getenv("LNS_FA_PPB") ? atoi(getenv("LNS_FA_PPB")) : 64;
+            int ppb = ppb_max;
+            while (ppb > 4 && (long)a.B * a.heads * ((a.C + ppb - 1) / ppb) < 1024) ppb >>= 1;
+            dim3 grid((a.C + ppb - 1) / ppb, a.heads, a.B);
+            const size_t ldsf = fa_sandwich_f_lds_bytes(HT, WT);
+            const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.u) & 15) == 0);
+            constexpr bool ULF = false;
+            if (vec && HT == WT && a.H == HT * 32 && a.W == WT * 32)
+                hipLaunchKernelGGL((fa_sandwich_f_kernel<HT, WT, true, (HT == WT), ULF>), grid, dim3(256), ldsf, s, a, ppb);
+            else if (vec) hipLaunchKernelGGL((fa_sandwich_f_kernel<HT, WT, true, false, ULF>), grid, dim3(256), ldsf, s, a, ppb);
+            else hipLaunchKernelGGL((fa_sandwich_f_kernel<HT, WT, false, false, ULF>), grid, dim3(256), ldsf, s, a, ppb);
+            return hipGetLastError();
+        }
+    }
     if (!fp32_only && (NWV == 4 || three_wave) && fa_sandwich_b_lds_bytes(HT, WT, NWV) <= 160 * 1024) {
         // planes per block: the Kx/Ky staging (load + split) is paid once per block, so as many planes as still leave
         // >= 2 blocks per CU
@@ -3877,6 +4197,15 @@ hipError_t init_kernels() {
     }
     LNS_SET_SWB(1, 1) LNS_SET_SWB(1, 2) LNS_SET_SWB(2, 1) LNS_SET_SWB(2, 2) LNS_SET_SWB(2, 3)
 #undef LNS_SET_SWB
+#define LNS_SET_SWF(HT, WT)                                                                                              \
+    {                                                                                                                    \
+        constexpr bool ULF = false;                                                                                      \
+        LNS_SET_LDS((fa_sandwich_f_kernel<HT, WT, true, (HT == WT), ULF>))                                               \
+        LNS_SET_LDS((fa_sandwich_f_kernel<HT, WT, true, false, ULF>))                                                    \
+        LNS_SET_LDS((fa_sandwich_f_kernel<HT, WT, false, false, ULF>))                                                   \
+    }
+    LNS_SET_SWF(1, 1) LNS_SET_SWF(1, 2) LNS_SET_SWF(2, 1) LNS_SET_SWF(2, 2) LNS_SET_SWF(2, 3)
+#undef LNS_SET_SWF
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))

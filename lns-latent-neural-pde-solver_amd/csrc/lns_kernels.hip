@@ -1058,6 +1058,9 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 
 template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
+    // (Two accumulators per tile -- hh' apart from hl' + lh' -- are part of the accuracy here: with all three products in
+    //  one fp32 accumulator the 64-step NS2d rollout is at 1.0e-4 of the reference instead of 2.7e-5 ... 4.8e-5, and three
+    //  blocks per CU at 168 registers spill; measured, not adopted.  The 1x1 kernels, K <= 512, do use one: CONVB1_ONEACC.)
     // SPL = 3: three bf16 terms, six products.  SPL = 2: two fp16 terms of the operand scaled by a power of two
     // (activations x the sample's dynamic scale in the staging, weights per layer on the host), three products hh' + (hl' + lh'); the
     // dropped ll' term is <= 2^-24 |xy|.  Half the MFMAs and 2/3 of the LDS bytes at the accuracy of an fp32 chain.
@@ -1389,9 +1392,16 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 // ===========================================================================
 // split scheme of the 1x1 kernels: 2 = two fp16 terms of the scaled operand (f16x2, see the 3x3 kernel), 3 = three bf16 terms
 #define CONVB1_SPL 2
+// 1: the three products of the f16x2 scheme go into ONE fp32 accumulator per tile (an fp32 chain's accuracy; 32 fewer
+// registers -> three blocks per CU for these memory-bound kernels).  0: hh' and hl' + lh' in separate accumulators.
+#ifndef LNS_CONV1_ONEACC
+#define LNS_CONV1_ONEACC 1
+#endif
+#define CONVB1_ONEACC (LNS_CONV1_ONEACC != 0)
+#define CONVB1_MIN_WAVES (LNS_CONV1_ONEACC ? 3 : 1)
 #define CONVB1_SLAB_BYTES (CONVB1_SPL * 4 * 64 * 16)   // splits x 4 octets x 64 couts x 8 ch
 template <bool VEC2, bool FUSE2>
-__global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1_bf16x3_kernel(ConvArgs a) {
     constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, SPL = CONVB1_SPL, NWU = CONVB1_SLAB_BYTES / 16 / 256;
     constexpr int XB = SPL * 4 * TN * 16;
     constexpr int BUF = XB + CONVB1_SLAB_BYTES;
@@ -1571,6 +1581,10 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
                     LNS_BX1(acc_lo, SPL - 1, 0)
                     LNS_BX1(acc_lo, 0, 1)
                     LNS_BX1(acc_lo, 1, 0)
+                } else if (CONVB1_ONEACC) {
+                    LNS_BX1(acc_hi, 0, 0)
+                    LNS_BX1(acc_hi, 0, 1)
+                    LNS_BX1(acc_hi, 1, 0)
                 } else {
                     LNS_BX1(acc_hi, 0, 0)
                     LNS_BX1(acc_lo, 0, 1)
@@ -1627,7 +1641,7 @@ __global__ __launch_bounds__(256, 1) void conv1_bf16x3_kernel(ConvArgs a) {
 // over `a.ct_per_block` cout tiles streaming only weight slabs.  Same accumulation order per output as the
 // streaming form (stage 0 then stage 1, k-steps in order), so either form gives the same bits.
 template <bool VEC2>
-__global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(ConvArgs a) {
     constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, SPL = CONVB1_SPL, NWU = CONVB1_SLAB_BYTES / 16 / 256;
     constexpr int XB = SPL * 4 * TN * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1788,6 +1802,10 @@ __global__ __launch_bounds__(256, 1) void conv1s_bf16x3_kernel(ConvArgs a) {
                 LNS_BX1(acc_lo, SPL - 1, 0)
                 LNS_BX1(acc_lo, 0, 1)
                 LNS_BX1(acc_lo, 1, 0)
+            } else if (CONVB1_ONEACC) {
+                LNS_BX1(acc_hi, 0, 0)
+                LNS_BX1(acc_hi, 0, 1)
+                LNS_BX1(acc_hi, 1, 0)
             } else {
                 LNS_BX1(acc_hi, 0, 0)
                 LNS_BX1(acc_lo, 0, 1)

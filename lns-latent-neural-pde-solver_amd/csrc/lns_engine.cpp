@@ -1189,6 +1189,34 @@ struct Runner {
                     if (!all_untagged(a.x, a.w, a.bias, a.ss, a.rowmap, a.colmap, a.y, a.res, a.badd, a.w2, a.bias2, a.wb, a.stat_part,
                                       a.amax_in, a.amax_out)) B.bad = true;
                     if (B.bad) break;
+#ifdef LNS_TS
+                    // diagnostic build: per-block phase timestamps of the layer named by $LNS_TS_LAYER, appended to $LNS_TS_FILE
+                    if (getenv("LNS_TS_FILE") && getenv("LNS_TS_LAYER") && op.name.find(getenv("LNS_TS_LAYER")) != std::string::npos &&
+                        (cv_is_split_3x3(op.variant) || op.variant == CV_B1)) {
+                        const long nblk = (long)a.tiles_x * a.tiles_y * a.cout_tiles * a.B;
+                        long long* dts = nullptr;
+                        if (hipMalloc(reinterpret_cast<void**>(&dts), nblk * 64) == hipSuccess) {
+                            (void)hipMemsetAsync(dts, 0, nblk * 64, stream);
+                            a.dbg_ts = dts;
+                            rc = launch_conv(op.variant, a, stream);
+                            (void)hipStreamSynchronize(stream);
+                            std::vector<long long> h(nblk * 8);
+                            (void)hipMemcpy(h.data(), dts, nblk * 64, hipMemcpyDeviceToHost);
+                            (void)hipFree(dts);
+                            if (FILE* f = fopen(getenv("LNS_TS_FILE"), "a")) {
+                                fprintf(f, "# launch %s B=%d Cin=%d Cout=%d H=%d W=%d blocks=%ld\n", op.name.c_str(), a.B, a.Cin, a.Cout, a.Hout, a.Wout, nblk);
+                                for (long i = 0; i < nblk; ++i) {
+                                    fprintf(f, "%ld", i);
+                                    for (int k = 0; k < 8; ++k) fprintf(f, " %lld", h[i * 8 + k]);
+                                    fprintf(f, "\n");
+                                }
+                                fclose(f);
+                            }
+                            break;
+                        }
+                    }
+                    a.dbg_ts = nullptr;
+#endif
                     rc = launch_conv(op.variant, a, stream);
                     break;
                 }

@@ -729,7 +729,11 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 // HW_ID, XCC_ID (tools/ts_analyze.py).  Expands to nothing in the shipped library.
 #ifdef LNS_TS
 #define LNS_TS_DECL long long ts_[6] = {0, 0, 0, 0, 0, 0};
+#if LNS_TS == 2
+#define LNS_TSTAMP(i) if ((i) == 5) { __builtin_amdgcn_sched_barrier(0); ts_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+#else
 #define LNS_TSTAMP(i) { __builtin_amdgcn_sched_barrier(0); ts_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+#endif
 #define LNS_TS_DUMP                                                                                   \
     __builtin_amdgcn_s_waitcnt(0);                                                                    \
     LNS_TSTAMP(5)                                                                                     \
@@ -744,6 +748,15 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 #define LNS_TSTAMP(i)
 #define LNS_TS_DUMP
 #endif
+// -DLNS_TS=2: the six slots are taken INSIDE the epilogue instead (start, after the activation, fused-conv weights in
+// LDS, fused conv done, stores issued, statistics done)
+#if defined(LNS_TS) && LNS_TS == 2
+#define LNS_ETS(i) if (ets) { __builtin_amdgcn_sched_barrier(0); ets[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+#define LNS_ETS_ARG , ts_
+#else
+#define LNS_ETS(i)
+#define LNS_ETS_ARG , nullptr
+#endif
 
 // Shared epilogue of the bf16x3 kernels (64-cout tile, wave = 64 couts x 32*NT pixels): sums the two
 // accumulators, then bias / per-sample add / activation / fused second 1x1 conv (fp32 MFMA, the
@@ -754,9 +767,20 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 template <int NT, bool FUSE2, int MT = 2>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
-                                               float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1) {
+                                               float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1, long long* ets = nullptr) {
     constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
     static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
+    // fused second conv: its weights are requested first, so that their L2 latency hides behind the first conv's epilogue
+    // arithmetic (they were loaded behind a barrier: 1 of the ~4 us the fused epilogue cost per block)
+    LNS_ETS(0)
+    float w2v[FUSE2 ? TM * TM / NTHR : 1];
+    if (FUSE2) {
+#pragma unroll
+        for (int u = 0; u < TM * TM / NTHR; ++u) {
+            const int i = tid + u * NTHR, k = i / TM, co2 = i - k * TM;      // fp32 pack [k = co1][Cout2_pad]
+            w2v[u] = a.w2[(long)k * a.Cout2_pad + co2];
+        }
+    }
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -772,7 +796,25 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     // epilogue arithmetic instead of one round trip per stored element (y may alias nothing, but the compiler
     // cannot know and would not move a load above an earlier store)
     float rv[MT][NT][16];
-    if (rb) {
+    if (rb && (long)a.Cout * HWo * 4 < (1L << 31)) {
+        // through a buffer descriptor of the sample's residual tensor, addressed like the stores below (lane offset in
+        // one VGPR, channel row in the scalar offset); what lies outside the tensor reads as zero and is never stored
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rb), 0, a.Cout * HWo * 4, 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned vo = pix[nt] >= 0 ? (unsigned)((4 * kh * HWo + pix[nt]) * 4) : 0x80000000u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = ct * TM + mt * 32 + (r & 3) + 8 * (r >> 2);
+                    // a row past Cout must not wrap into range through the scalar offset (it is outside the range check)
+                    rv[mt][nt][r] = row + 4 < a.Cout || (ct + 1) * TM <= a.Cout
+                                        ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)vo, row * HWo * 4, 0))
+                                        : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)(vo + (unsigned)(row * HWo * 4)), 0, 0));
+                }
+        }
+    } else if (rb) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -843,6 +885,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = swish_f(acc[mt][nt][r]);
     }
+    LNS_ETS(1)
     if (FUSE2) {
         // Second 1x1 conv (64 -> 64) on the same split-operand scheme: the accumulator tile Y1 (channels in
         // registers, pixels on lanes) is scaled, split into two fp16 terms IN REGISTERS and is the B operand
@@ -854,25 +897,21 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
         float* b2s = reinterpret_cast<float*>(W2s + 2 * TM * W2W);      // [TM] bias of the second conv
         __syncthreads();
         {
-            float v[TM * TM / NTHR];
-#pragma unroll
-            for (int u = 0; u < TM * TM / NTHR; ++u) {
-                const int i = tid + u * NTHR, k = i / TM, co2 = i - k * TM;      // fp32 pack [k = co1][Cout2_pad]
-                v[u] = a.w2[(long)k * a.Cout2_pad + co2] * a.w2scale;
-            }
 #pragma unroll
             for (int u = 0; u < TM * TM / NTHR; ++u) {
                 const int i = tid + u * NTHR, k = i / TM, co2 = i - k * TM;
                 const int w = k & 15;
                 const int kp = (k & ~15) | (w & 3) | (((w >> 3) & 1) << 2) | (((w >> 2) & 1) << 3);
-                const _Float16 hh = (_Float16)v[u];
-                const _Float16 ll = (_Float16)(v[u] - (float)hh);
+                const float wv = w2v[u] * a.w2scale;
+                const _Float16 hh = (_Float16)wv;
+                const _Float16 ll = (_Float16)(wv - (float)hh);
                 W2s[(0 * TM + co2) * W2W + kp] = __builtin_bit_cast(unsigned short, hh);
                 W2s[(1 * TM + co2) * W2W + kp] = __builtin_bit_cast(unsigned short, ll);
             }
             if (tid < TM) b2s[tid] = a.bias2 ? a.bias2[tid] : 0.0f;
         }
         __syncthreads();
+        LNS_ETS(2)
         const char* w2a = reinterpret_cast<const char*>(W2s) + (l31 * W2W + 8 * kh) * 2;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -918,6 +957,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     acc[m2][nt][r] = ((a2h[m2][r] + a2l[m2][r]) * w2inv) * inv2 + b2s[m2 * 32 + drow(r, kh)];
         }
     }
+    LNS_ETS(3)
     // GroupNorm statistics of the stored tile (planner: only when the 128-pixel tiles cover the plane exactly, so
     // every pixel of the tile is valid): the tile goes through LDS as [channel][pixel], four threads per channel
     // take 32 pixels each (two-pass mean / centred second moment in registers) and merge pairwise (Chan et al.).
@@ -1019,6 +1059,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             }
         }
     }
+    LNS_ETS(4)
     if (stats) {
         __syncthreads();
         const int c = tid >> 2, q = tid & 3;
@@ -1375,7 +1416,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     unsigned am = 0u;
     LNS_TSTAMP(3)
     convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am,
-                                  (a.bias || a.badd) ? addv : nullptr);
+                                  (a.bias || a.badd) ? addv : nullptr, -1 LNS_ETS_ARG);
     LNS_TSTAMP(4)
     if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);    // wmax: free since the prologue
     LNS_TS_DUMP
@@ -1401,7 +1442,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #define CONVB1_MIN_WAVES (LNS_CONV1_ONEACC ? 3 : 1)
 #define CONVB1_SLAB_BYTES (CONVB1_SPL * 4 * 64 * 16)   // splits x 4 octets x 64 couts x 8 ch
 template <bool VEC2, bool FUSE2>
-__global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1_bf16x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN_WAVES) : CONVB1_MIN_WAVES) void conv1_bf16x3_kernel(ConvArgs a) {   // (the fused second conv needs the registers: two blocks per CU)
     constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, SPL = CONVB1_SPL, NWU = CONVB1_SLAB_BYTES / 16 / 256;
     constexpr int XB = SPL * 4 * TN * 16;
     constexpr int BUF = XB + CONVB1_SLAB_BYTES;
@@ -1630,7 +1671,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1_bf16x3_kernel(Con
     }
     unsigned am = 0u;
     LNS_TSTAMP(3)
-    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am, (a.bias || a.badd) ? addv : nullptr);
+    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am, (a.bias || a.badd) ? addv : nullptr, -1 LNS_ETS_ARG);
     LNS_TSTAMP(4)
     if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);
     LNS_TS_DUMP

@@ -27,6 +27,8 @@ cases = {
     "k1_inproj": dict(B=64, Cin=64, Cout=512, H=64, W=64, k=1, ss=True, act=0, v=8),    # input-stationary form
     "k1_toout": dict(B=64, Cin=512, Cout=64, H=64, W=64, k=1, ss=True, act=0),
     "k1_128": dict(B=64, Cin=64, Cout=64, H=128, W=128, k=1, ss=True, act=1),
+    "k1_toout_gelu": dict(B=64, Cin=512, Cout=64, H=64, W=64, k=1, ss=True, act=0, act_out=2),
+    "k1_toout_gelu_res": dict(B=64, Cin=512, Cout=64, H=64, W=64, k=1, ss=True, act=0, act_out=2, res=True),
     "lat_d4": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0, dil=4),
     "lat_b256": dict(B=256, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0),
 }
@@ -68,9 +70,10 @@ for name in which:
     dil = c.get("dil", 1)
     p = dil * (k - 1) // 2
     y = torch.empty(B, Cout, Hv, Wv, device="cuda")
+    res = torch.randn(B, Cout, Hv, Wv, device="cuda") if c.get("res") else None
     def run():
         rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, Hv, Wv, gc._hp(w), gc._hp(bias), Cout, k, 1, dil, p, p, p, p, 1, 1,
-                             ss.data_ptr(), c["act"], 0, None, None, y.data_ptr(), c.get("v", VARIANT if k == 3 else 7), None, None)
+                             ss.data_ptr(), c["act"], c.get("act_out", 0), res.data_ptr() if res is not None else None, None, y.data_ptr(), c.get("v", VARIANT if k == 3 else 7), None, None)
         assert rc == 0
     for _ in range(NREP):
         run()

@@ -12,7 +12,7 @@ KERNELS = {   # class -> (substring of the kernel name, apply the guide's x2 FET
     "conv3x3": ("conv3_bf16x3_kernel<1, 1, false, 2, 2>", False),
     "conv1x1": ("conv1_bf16x3_kernel<true, false>", False),
     "conv1x1_stationary": ("conv1s_bf16x3_kernel", False),
-    "fa_sandwich": ("fa_sandwich_b_kernel<2, 2, true, true", True),
+    "fa_sandwich": ("fa_sandwich_f_kernel<2, 2, true, true", True),
 }
 
 

@@ -1681,6 +1681,8 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
 // the pixel tile is transformed, split and staged ONCE (it fits the two stage buffers), then the block walks
 // over `a.ct_per_block` cout tiles streaming only weight slabs.  Same accumulation order per output as the
 // streaming form (stage 0 then stage 1, k-steps in order), so either form gives the same bits.
+// (three waves per SIMD although the 168-register budget spills 62 registers outside the loop: the in_proj shape runs
+//  166 us that way and 195 us at two waves without spills)
 template <bool VEC2>
 __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(ConvArgs a) {
     constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, SPL = CONVB1_SPL, NWU = CONVB1_SLAB_BYTES / 16 / 256;
@@ -3029,7 +3031,7 @@ hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s) {
 // accumulator registers (two-pass, exact) and applied before the store.
 // ===========================================================================
 template <int HT, int WT, bool VEC>
-__global__ __launch_bounds__(256, (HT * WT >= 6 ? 1 : 2)) void fa_sandwich_kernel(FaSandwichArgs a, int planes_per_block) {
+__global__ __launch_bounds__(256, (HT * WT >= 6 || (HT * WT >= 4 && !VEC) ? 1 : 2)) void fa_sandwich_kernel(FaSandwichArgs a, int planes_per_block) {   // (scalar-load form of the 64 x 64 planes: the whole register file instead of spills)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HP = HT * 32 + 1, WP = WT * 32 + 1;
     // plane prefetch registers: one 64-lane wave moves a whole (padded) plane, 32 rows at a time
@@ -3475,7 +3477,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fa_sandwich_b_kernel(FaSandwichAr
 // the SW decoder (WT = 3, 111 KB) run one block per CU with the whole register file.
 // ---------------------------------------------------------------------------
 template <int HT, int WT, bool VEC, bool FULL, bool ULOOP>
-__global__ __launch_bounds__(256, (WT <= 2 ? 2 : 1)) void fa_sandwich_f_kernel(FaSandwichArgs a, int planes_per_block) {
+__global__ __launch_bounds__(256, (WT <= 2 && (VEC || HT * WT < 4) ? 2 : 1)) void fa_sandwich_f_kernel(FaSandwichArgs a, int planes_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SPL = 2, NWV = 4;
     constexpr int HB = HT * 32, WB = WT * 32, NTHR = 64 * NWV;

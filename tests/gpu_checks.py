@@ -291,12 +291,26 @@ def attention_case(B, heads, D, n, seed=0):
     return rel_l2(out, ref)
 
 
-def sandwich_case(B, heads, C, H, W, instnorm=True, seed=0):
+def sandwich_case(B, heads, C, H, W, instnorm=True, seed=0, uscale=1.0, kscale=1.0, plane_spread=0.0, heavy_k=False,
+                  sample_scales=None, fp64=False):
+    """rel. L2 of lns_op_fa_sandwich vs the oracle.  uscale / kscale: magnitude of the planes / of Kx, Ky; plane_spread:
+    the channel planes of a sample differ by up to 10^(+-plane_spread) in magnitude (the f16x2 form scales by the
+    SAMPLE's maximum); heavy_k: heavy-tailed (Student-t, 2 dof) kernels, i.e. large absolute row sums against their
+    typical entry (the bound of U); sample_scales: per-sample factors; fp64: also returns the error against fp64."""
     L = _lib.lib()
     r = rng(seed)
     u = r.standard_normal((B, heads * C, H, W)).astype(np.float32)
-    kx = (r.standard_normal((B, heads, H, H)) / np.sqrt(H)).astype(np.float32)
-    ky = (r.standard_normal((B, heads, W, W)) / np.sqrt(W)).astype(np.float32)
+    if plane_spread:
+        u = (u * (10.0 ** r.uniform(-plane_spread, plane_spread, size=(B, heads * C, 1, 1)))).astype(np.float32)
+    u = (u * np.float32(uscale)).astype(np.float32)
+    if sample_scales is not None:
+        u = (u * np.asarray(sample_scales, np.float32).reshape(B, 1, 1, 1)).astype(np.float32)
+    if heavy_k:
+        kx = (r.standard_t(2.0, size=(B, heads, H, H)) / np.sqrt(H) * kscale).astype(np.float32)
+        ky = (r.standard_t(2.0, size=(B, heads, W, W)) / np.sqrt(W) * kscale).astype(np.float32)
+    else:
+        kx = (r.standard_normal((B, heads, H, H)) / np.sqrt(H) * kscale).astype(np.float32)
+        ky = (r.standard_normal((B, heads, W, W)) / np.sqrt(W) * kscale).astype(np.float32)
     ref = lns_oracle.fa_contract(u, kx, ky, heads)
     if instnorm:
         ref = lns_oracle.groupnorm(ref, heads * C, 1e-5)
@@ -307,7 +321,16 @@ def sandwich_case(B, heads, C, H, W, instnorm=True, seed=0):
     assert rc == 0
     out = o.cpu().numpy()
     assert np.isfinite(out).all()
-    return rel_l2(out, ref)
+    # every sample on its own (samples of one batch may differ by orders of magnitude)
+    err = max(rel_l2(out[i], ref[i]) for i in range(B))
+    if fp64:
+        ud64 = u.astype(np.float64).reshape(B, heads, C, H, W)
+        r64 = np.einsum("bhij,bhcjm,bhlm->bhcil", kx.astype(np.float64), ud64, ky.astype(np.float64)).reshape(B, heads * C, H, W)
+        if instnorm:
+            mu = r64.mean(axis=(2, 3), keepdims=True)
+            r64 = (r64 - mu) / np.sqrt(r64.var(axis=(2, 3), keepdims=True) + 1e-5)
+        return err, max(rel_l2(out[i], r64[i].astype(np.float32)) for i in range(B))
+    return err
 
 
 def build_models(args, weight_seed):

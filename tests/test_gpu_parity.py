@@ -120,6 +120,22 @@ def test_fa_sandwich_kernel(case):
     assert gc.sandwich_case(**case) < KERNEL_TOL
 
 
+@pytest.mark.parametrize("case", [
+    dict(uscale=1e-5), dict(uscale=3e3), dict(kscale=1e-3), dict(kscale=50.0), dict(heavy_k=True),
+    dict(sample_scales=[1e-4, 2e3]), dict(plane_spread=2.0), dict(plane_spread=2.0, heavy_k=True, uscale=30.0)])
+def test_fa_sandwich_f16x2_domain(case):
+    """The f16x2 sandwich scales P by the sample's max |u|, Kx / Ky by their maxima and U by max|P| x the largest absolute
+    row sum of Ky: no input range, samples independent, planes far below the sample's maximum still normalise correctly.
+    Checked against the oracle and against an fp64 evaluation of the same contraction (the tie-breaker)."""
+    _need_gpu()
+    import gpu_checks as gc
+    for shape in (dict(B=2, heads=4, C=16, H=64, W=64), dict(B=2, heads=2, C=8, H=48, W=96)):
+        err, e64 = gc.sandwich_case(seed=11, fp64=True, **shape, **case)
+        # planes three to four decades below the sample's maximum keep fewer bits of the split: 1e-5 there, 2e-6 otherwise
+        tol = 1e-5 if case.get("plane_spread") else KERNEL_TOL
+        assert err < tol and e64 < tol, (shape, case, err, e64)
+
+
 @pytest.mark.parametrize("preset", ["ns2d_mini", "ns2d_128", "sw_half_periodic", "sw_96x192x5", "twophase",
                                     "twophase_cond"])
 def test_every_layer_matches_oracle(preset):

@@ -2482,17 +2482,37 @@ __global__ __launch_bounds__(256) void ln_pe_kernel(LnPeArgs a) {
     const bool ok = i < a.n;
     const int cq = (a.C + 3) / 4, c_lo = qd * cq, c_hi = min(a.C, c_lo + cq);
     const float* xs = a.x + (long)b * a.x_bs + (ok ? i : 0);
+    // C <= 128: the thread's quarter of the channel vector stays in registers -- ONE pass over x, all its loads (and those of
+    // gamma / beta / the positional table) in flight together instead of three dependent sweeps (33 -> 9 us at 128 x 256)
+    constexpr int CQ = 32;
+    const bool in_regs = cq <= CQ;
+    float xv[CQ];
     float s = 0.0f;
-    for (int c = c_lo; c < c_hi; ++c) s += xs[(long)c * a.n];
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < CQ; ++u) xv[u] = c_lo + u < c_hi ? xs[(long)(c_lo + u) * a.n] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < CQ; ++u) s += xv[u];            // (same order as the loop below)
+    } else {
+        for (int c = c_lo; c < c_hi; ++c) s += xs[(long)c * a.n];
+    }
     red[qd][lane] = s;
     __syncthreads();
     if (qd == 0) stat[0][lane] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)a.C;
     __syncthreads();
     const float mean = stat[0][lane];
     float q = 0.0f;
-    for (int c = c_lo; c < c_hi; ++c) {
-        const float d = xs[(long)c * a.n] - mean;
-        q += d * d;
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < CQ; ++u) {
+            const float d = xv[u] - mean;
+            q += c_lo + u < c_hi ? d * d : 0.0f;
+        }
+    } else {
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float d = xs[(long)c * a.n] - mean;
+            q += d * d;
+        }
     }
     red[qd][lane] = q;
     __syncthreads();
@@ -2502,6 +2522,24 @@ __global__ __launch_bounds__(256) void ln_pe_kernel(LnPeArgs a) {
     const float rstd = stat[1][lane];
     if (!ok) return;
     float* hs = a.h + (long)b * a.C * a.n + i;
+    if (in_regs) {
+        float ga[CQ], be[CQ], pe[CQ];
+#pragma unroll
+        for (int u = 0; u < CQ; ++u) {
+            const int c = c_lo + u < c_hi ? c_lo + u : c_lo;
+            ga[u] = a.gamma[c]; be[u] = a.beta[c];
+            pe[u] = a.pe_t ? a.pe_t[(long)c * a.pe_stride + i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < CQ; ++u) {
+            if (c_lo + u < c_hi) {
+                float v = (xv[u] - mean) * rstd * ga[u] + be[u];
+                if (a.pe_t) v += pe[u];
+                hs[(long)(c_lo + u) * a.n] = v;
+            }
+        }
+        return;
+    }
     for (int c = c_lo; c < c_hi; ++c) {
         float v = (xs[(long)c * a.n] - mean) * rstd * a.gamma[c] + a.beta[c];
         if (a.pe_t) v += a.pe_t[(long)c * a.pe_stride + i];

@@ -546,6 +546,7 @@ struct Planner {
             op.type = OP_ATTN; op.name = l.name + ".attn"; op.cls = CLS_ATTN;
             op.at.qkv = as_ptr<const float>(qkv.ptr); op.at.B = B; op.at.heads = l.heads; op.at.D = l.dim_head;
             op.at.n = n; op.at.scale = (float)std::pow((double)l.dim_head, -0.5); op.at.o = as_ptr<float>(o.ptr);
+            op.at.amax_in = qkv.amax ? as_ptr<const unsigned>(qkv.amax) : nullptr;
             op.flops = 4.0 * B * l.heads * (double)n * n * l.dim_head;
             op.bytes = 4.0 * B * 4.0 * inner * n;
             plan->ops.push_back(op);
@@ -1238,7 +1239,7 @@ struct Runner {
                     rc = launch_ln_pe(a, stream);
                     break;
                 }
-                case OP_ATTN: { AttnArgs a = op.at; fix(a.qkv, B); fix(a.o, B); rc = launch_attention(a, stream); break; }
+                case OP_ATTN: { AttnArgs a = op.at; fix(a.qkv, B); fix(a.o, B); fix(a.amax_in, B); rc = launch_attention(a, stream); break; }
                 case OP_FAPOOL: { FaPoolArgs a = op.fp; fix(a.v, B); fix(a.mx, B); fix(a.my, B); rc = launch_fa_pool(a, stream); break; }
                 case OP_FARED: {
                     FaReducerArgs a = op.fr;
@@ -2116,10 +2117,18 @@ int lns_op_groupnorm_stats(const float* x, int B, int C, int HW, int groups, flo
 
 int lns_op_attention(const float* qkv, int B, int heads, int dim_head, int n, float scale, float* o, void* stream) {
     if (!qkv || !o) return LNS_EINVAL;
-    AttnArgs a = {qkv, B, heads, dim_head, n, scale, o};
+    AttnArgs a = {qkv, B, heads, dim_head, n, scale, o, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    OPCHK(launch_attention(a, s));
-    OPCHK(hipStreamSynchronize(s));
+    // max |qkv| per sample (what the qkv convolution records inside a plan): enables the f16x2 form
+    unsigned* damax = nullptr;
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&damax), (size_t)B * LNS_AMAX_SUB * 4));
+    const long per = 3L * heads * dim_head * n;
+    hipError_t he = hipMemsetAsync(damax, 0, (size_t)B * LNS_AMAX_SUB * 4, s);
+    if (he == hipSuccess) he = launch_amax(qkv, per, per, B, damax, s);
+    if (he == hipSuccess) { a.amax_in = damax; he = launch_attention(a, s); }
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    (void)hipFree(damax);
+    OPCHK(he);
     return LNS_OK;
 }
 

@@ -146,7 +146,8 @@ struct LnPeArgs {
 hipError_t launch_ln_pe(const LnPeArgs& a, hipStream_t s);
 
 // softmax attention, channel-major qkv [B, 3*heads*D, n] -> o [B, heads*D, n]
-struct AttnArgs { const float* qkv; int B, heads, D, n; float scale; float* o; };
+struct AttnArgs { const float* qkv; int B, heads, D, n; float scale; float* o;
+                  const unsigned* amax_in; };   // [B][LNS_AMAX_SUB] max |qkv| per sample or null: enables the f16x2 form
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
 // FABlock2D pieces ----------------------------------------------------------

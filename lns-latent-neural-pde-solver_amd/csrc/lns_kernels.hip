@@ -2659,8 +2659,181 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same attention on the two-term fp16 split (f16x2): q, k, v multiplied by the power of two that puts the sample's
+// max |qkv| (amax side channel of the qkv convolution) at [2^14, 2^15), the softmax weights (<= 1) by 2^14; three
+// v_mfma_f32_32x32x16_f16 per product instead of eight v_mfma_f32_32x32x2_f32 (24 x 32 instead of 64 x 64 matrix
+// cycles per 32-key tile and wave), one accumulator per tile.
+//   S^T[key][query] = sum_d K[key][d] Q[d][query]: K tile in LDS as [key][d] (8 consecutive d per 16-byte unit), Q in
+//        registers (lane = query, 8 consecutive d per k-step and lane half);
+//   O^T[d][query] += sum_key V[d][key] P^T[key][query]: the S^T accumulator registers 8t'..8t'+7 of a lane half hold keys
+//        16t' + 4kh + {0..3, 8..11}; V is stored with its keys permuted inside every 16-block so that these are 8
+//        consecutive k positions of the A operand (the trick of the sandwich's second product), P is split in registers.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void attention_f_kernel(AttnArgs a) {
+    constexpr int KW = D + 8, VW = 32 + 8;                  // row strides in fp16 elements (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2 * 32 * KW];     // [split][key][d]
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[2 * D * VW];      // [split][d][permuted key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int n = a.n;
+    const long inner = (long)a.heads * D;
+    const float* qb = a.qkv + ((long)b * 3 * inner + (long)h * D) * n;
+    const float* kb = qb + inner * n;
+    const float* vb = kb + inner * n;
+    const int query = (blockIdx.x * 4 + wave) * 32 + l31;
+    const bool qvalid = query < n;
+    float sinv;
+    const float sc = f16x2_scale(amax_load(a.amax_in, b), sinv);       // one scale for q, k, v: max |qkv| of the sample
+    constexpr float SP = 16384.0f, SPINV = 1.0f / 16384.0f;
+
+    // Q: k-step t, lane half kh <-> d = 16t + 8kh + 0..7
+    uint4 qh[D / 16], ql[D / 16];
+    {
+        float qv[D / 16][8];
+#pragma unroll
+        for (int t = 0; t < D / 16; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[t][e] = qvalid ? qb[(long)(16 * t + 8 * kh + e) * n + query] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < D / 16; ++t) {
+            unsigned hq[4], lq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_pair_f16(qv[t][2 * e] * sc, qv[t][2 * e + 1] * sc, hq[e], lq[e]);
+            qh[t] = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+            ql[t] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+        }
+    }
+    float m = -INFINITY, l = 0.0f;
+    f32x16 oacc[D / 32];
+#pragma unroll
+    for (int mt = 0; mt < D / 32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.0f;
+
+    const int ntile = (n + 31) / 32;
+    // staging units: K -- (key = tid & 31, d octet = tid >> 5): 8 values strided by n; V -- (d = tid >> 2, key octet = tid & 3):
+    // 8 consecutive keys.  D = 64: one unit of each per thread; D = 32: threads >= 128 idle.
+    constexpr bool ALL = D == 64;
+    const int kkey = tid & 31, koct = tid >> 5;
+    const int vd = tid >> 2, voct = tid & 3;
+    const bool kact = ALL || koct < D / 8, vact = ALL || vd < D;
+    float kpre[8], vpre[8];
+    auto fetch = [&](int kt) __attribute__((always_inline)) {
+        const int key = kt * 32 + kkey;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kpre[e] = (kact && key < n) ? kb[(long)(8 * koct + e) * n + key] : 0.0f;
+        const int k0 = kt * 32 + 8 * voct;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vpre[e] = (vact && k0 + e < n) ? vb[(long)vd * n + k0 + e] : 0.0f;
+    };
+    fetch(0);
+    const char* ka = reinterpret_cast<const char*>(Ks) + (l31 * KW + 8 * kh) * 2;        // + s*32*KW*2 + t*32
+    const char* va = reinterpret_cast<const char*>(Vs) + (l31 * VW + 8 * kh) * 2;        // + (s*D + mt*32)*VW*2 + t'*32
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int key0 = kt * 32;
+        __syncthreads();
+        if (kact) {
+            unsigned hq[4], lq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_pair_f16(kpre[2 * e] * sc, kpre[2 * e + 1] * sc, hq[e], lq[e]);
+            *reinterpret_cast<uint4*>(Ks + (0 * 32 + kkey) * KW + 8 * koct) = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+            *reinterpret_cast<uint4*>(Ks + (1 * 32 + kkey) * KW + 8 * koct) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+        }
+        if (vact) {
+            unsigned hq[4], lq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_pair_f16(vpre[2 * e] * sc, vpre[2 * e + 1] * sc, hq[e], lq[e]);
+            // keys 8o..8o+3 and 8o+4..8o+7 of a 16-block go to positions (quad 0 -> 0, quad 1 -> 8, quad 2 -> 4, quad 3 -> 12)
+            const int blk = (voct >> 1) * 16, p0 = blk + (voct & 1) * 4, p1 = p0 + 8;
+            *reinterpret_cast<uint2*>(Vs + (0 * D + vd) * VW + p0) = make_uint2(hq[0], hq[1]);
+            *reinterpret_cast<uint2*>(Vs + (0 * D + vd) * VW + p1) = make_uint2(hq[2], hq[3]);
+            *reinterpret_cast<uint2*>(Vs + (1 * D + vd) * VW + p0) = make_uint2(lq[0], lq[1]);
+            *reinterpret_cast<uint2*>(Vs + (1 * D + vd) * VW + p1) = make_uint2(lq[2], lq[3]);
+        }
+        __syncthreads();
+        if (kt + 1 < ntile) fetch(kt + 1);
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < D / 16; ++t) {
+            const f16x8 kh_ = *reinterpret_cast<const f16x8*>(ka + t * 32);
+            const f16x8 kl_ = *reinterpret_cast<const f16x8*>(ka + 32 * KW * 2 + t * 32);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_, __builtin_bit_cast(f16x8, qh[t]), sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_, __builtin_bit_cast(f16x8, ql[t]), sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl_, __builtin_bit_cast(f16x8, qh[t]), sacc, 0, 0, 0);
+        }
+        const float sscale = (a.scale * sinv) * sinv;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + drow(r, kh);
+            float sv = sacc[r] * sscale;
+            if (key >= n) sv = -INFINITY;
+            sacc[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m - mnew) * 1.44269504088896341f);
+        float lt = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f((sacc[r] - mnew) * 1.44269504088896341f);
+            sacc[r] = p;
+            lt += p;
+        }
+        lt += __shfl_xor(lt, 32);
+        l = l * alpha + lt;
+        m = mnew;
+        // P^T split in registers: k-step t' <-> accumulator registers 8t'..8t'+7
+        uint4 ph[2], pl[2];
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            unsigned hq[4], lq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_pair_f16(sacc[8 * tp + 2 * e] * SP, sacc[8 * tp + 2 * e + 1] * SP, hq[e], lq[e]);
+            ph[tp] = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+            pl[tp] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+        }
+        // the accumulator carries the factor sc * 2^14 of its operands; alpha rescales it like the plain one
+#pragma unroll
+        for (int mt = 0; mt < D / 32; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const f16x8 vh_ = *reinterpret_cast<const f16x8*>(va + (0 * D + mt * 32) * (VW * 2) + tp * 32);
+                const f16x8 vl_ = *reinterpret_cast<const f16x8*>(va + (1 * D + mt * 32) * (VW * 2) + tp * 32);
+                oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, __builtin_bit_cast(f16x8, ph[tp]), oacc[mt], 0, 0, 0);
+                oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, __builtin_bit_cast(f16x8, pl[tp]), oacc[mt], 0, 0, 0);
+                oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_, __builtin_bit_cast(f16x8, ph[tp]), oacc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (qvalid) {
+        const float inv = (SPINV * sinv) / l;
+        float* ob = a.o + ((long)b * inner + (long)h * D) * n + query;
+#pragma unroll
+        for (int mt = 0; mt < D / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[(long)(mt * 32 + drow(r, kh)) * n] = oacc[mt][r] * inv;
+    }
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.n + 127) / 128, a.heads, a.B);
+    // f16x2 form where the producer recorded max |qkv| per sample (a per-layer condition); LNS_ATTN_FP32 keeps fp32 MFMA
+    static const bool fp32_only = getenv("LNS_ATTN_FP32") != nullptr;
+    if (a.amax_in && !fp32_only) {
+        if (a.D == 64) hipLaunchKernelGGL(attention_f_kernel<64>, grid, dim3(256), 0, s, a);
+        else if (a.D == 32) hipLaunchKernelGGL(attention_f_kernel<32>, grid, dim3(256), 0, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (a.D == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, a);
     else if (a.D == 32) hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, a);
     else return hipErrorInvalidValue;

@@ -272,10 +272,17 @@ def gn_case(B, C, HW, groups, eps, premul=False, seed=0):
     return rel_l2(out, ref)
 
 
-def attention_case(B, heads, D, n, seed=0):
+def attention_case(B, heads, D, n, seed=0, qk_scale=1.0, v_scale=1.0, sample_scales=None, fp64=False):
+    """rel. L2 of lns_op_attention vs the oracle.  qk_scale / v_scale: magnitude of q, k / of v (the f16x2 form scales all
+    three by the sample's max |qkv|: a large v leaves q, k far below the maximum, a large q k^T saturates the softmax);
+    sample_scales: per-sample factors on v; fp64: also returns the error against an fp64 evaluation."""
     L = _lib.lib()
     r = rng(seed)
     qkv = r.standard_normal((B, 3, heads, D, n)).astype(np.float32)
+    qkv[:, :2] *= np.float32(qk_scale)
+    qkv[:, 2] *= np.float32(v_scale)
+    if sample_scales is not None:
+        qkv[:, 2] *= np.asarray(sample_scales, np.float32).reshape(B, 1, 1, 1)
     q = np.ascontiguousarray(qkv[:, 0].transpose(0, 1, 3, 2))  # b h n d
     k = np.ascontiguousarray(qkv[:, 1].transpose(0, 1, 3, 2))
     v = np.ascontiguousarray(qkv[:, 2].transpose(0, 1, 3, 2))
@@ -288,7 +295,16 @@ def attention_case(B, heads, D, n, seed=0):
     assert rc == 0
     out = o.cpu().numpy()
     assert np.isfinite(out).all()
-    return rel_l2(out, ref)
+    err = max(rel_l2(out[i], ref[i]) for i in range(B))
+    if fp64:
+        q64, k64, v64 = q.astype(np.float64), k.astype(np.float64), v.astype(np.float64)
+        s64 = np.einsum("bhid,bhjd->bhij", q64, k64) * scale
+        s64 -= s64.max(axis=-1, keepdims=True)
+        p64 = np.exp(s64)
+        p64 /= p64.sum(axis=-1, keepdims=True)
+        r64 = np.einsum("bhij,bhjd->bhid", p64, v64).transpose(0, 1, 3, 2)
+        return err, max(rel_l2(out[i], r64[i].astype(np.float32)) for i in range(B))
+    return err
 
 
 def sandwich_case(B, heads, C, H, W, instnorm=True, seed=0, uscale=1.0, kscale=1.0, plane_spread=0.0, heavy_k=False,

@@ -110,6 +110,19 @@ def test_attention_kernel(case):
 
 
 @pytest.mark.parametrize("case", [
+    dict(qk_scale=1e-3, v_scale=1e-3), dict(qk_scale=1.0, v_scale=1e3), dict(qk_scale=4.0), dict(qk_scale=0.05, v_scale=200.0),
+    dict(sample_scales=[1e-4, 3e3])])
+def test_attention_f16x2_domain(case):
+    """q, k, v share one power-of-two scale per sample (max |qkv|): values far below the maximum, saturated and flat
+    softmaxes, samples of very different magnitude -- against the oracle and an fp64 evaluation."""
+    _need_gpu()
+    import gpu_checks as gc
+    for shape in (dict(B=2, heads=4, D=64, n=256), dict(B=2, heads=2, D=32, n=80)):
+        err, e64 = gc.attention_case(seed=21, fp64=True, **shape, **case)
+        assert err < KERNEL_TOL and e64 < KERNEL_TOL, (shape, case, err, e64)
+
+
+@pytest.mark.parametrize("case", [
     dict(B=2, heads=8, C=64, H=64, W=64), dict(B=2, heads=8, C=64, H=32, W=32),
     dict(B=1, heads=8, C=64, H=24, W=48), dict(B=1, heads=8, C=64, H=48, W=96),
     dict(B=2, heads=2, C=32, H=16, W=16), dict(B=2, heads=2, C=32, H=8, W=8),

@@ -395,7 +395,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_strict_fp32:
         # the same workload with every convolution / the FABlock sandwich on the exact-fp32 matrix instruction
         # (v_mfma_f32_32x32x2_f32): a child process, because the arithmetic is chosen when the library packs the weights
-        env = dict(os.environ, LNS_CONV_FP32_MFMA="1", LNS_CONV1_FP32_MFMA="1", LNS_FA_SANDWICH_FP32="1")
+        env = dict(os.environ, LNS_CONV_FP32_MFMA="1", LNS_CONV1_FP32_MFMA="1", LNS_FA_SANDWICH_FP32="1", LNS_ATTN_FP32="1")
         cmd = [sys.executable, os.path.abspath(__file__), "--strict-fp32-child", "--preset", a.preset, "--batch", str(B),
                "--rollout", str(T), "--steps", str(max(1, min(a.steps, 3))), "--warmup", "1"]
         if a.device is not None:

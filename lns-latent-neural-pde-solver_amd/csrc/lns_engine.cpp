@@ -569,8 +569,8 @@ struct Planner {
             const float t = pos * 64.0f;
             for (int d = 0; d < half; ++d) {
                 const float f = t * p.host[d];
-                cs[((size_t)i * half + d) * 2] = (float)std::cos((double)f);
-                cs[((size_t)i * half + d) * 2 + 1] = (float)std::sin((double)f);
+                cs[((size_t)d * n + i) * 2] = (float)std::cos((double)f);            // [half][n][2]: a wave reads one frequency's
+                cs[((size_t)d * n + i) * 2 + 1] = (float)std::sin((double)f);        // row, positions on consecutive lanes
             }
         }
         return const_floats(cs);

@@ -176,7 +176,7 @@ hipError_t launch_fa_reducer2(const FaReducerArgs& ax, const FaReducerArgs& ay, 
 struct FaLrkArgs {                     // rotary + q k^T
     const float* qk;                   // [B, 2*heads*DK, n]
     int B, heads, DK, n;
-    const float* cs;                   // [n][DK/2][2] (cos, sin)
+    const float* cs;                   // [DK/2][n][2] (cos, sin), frequency-major
     float* kmat;                       // [B, heads, n, n]
 };
 hipError_t launch_fa_lrk(const FaLrkArgs& a, hipStream_t s);

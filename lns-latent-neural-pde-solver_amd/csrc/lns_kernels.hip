@@ -3165,31 +3165,32 @@ __device__ __forceinline__ void fa_lrk_body(const FaLrkArgs& a, char* smem) {
     const float* qb = a.qk + ((long)b * 2 * a.heads * DK + (long)h * DK) * n;
     const float* kb = qb + (long)a.heads * DK * n;
     const int tid = threadIdx.x;
-    for (int base = 0; base < DK * npad; base += 256 * 8) {      // 8 elements (48 loads) in flight per thread
-        // branch-free loads (clamped indices) so that all 48 are issued before the first use
+    // rotary embedding of q and k into LDS.  A thread takes the PAIR (d, d + half) of a position: both outputs need the
+    // same two inputs and the same (cos, sin) entry, so every input is loaded once, every load is a run of consecutive
+    // positions of one row (the table is frequency-major), and a thread's 40 loads are in flight together.
+    for (int base = 0; base < half * npad; base += 256 * 8) {
         float c_[8], s_[8], q0[8], q1[8], k0[8], k1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + tid + u * 256;
             const int d = i / npad, j = i - d * npad;
-            const bool ok = i < DK * npad && j < n;
+            const bool ok = i < half * npad && j < n;
             const int dd = ok ? d : 0, jj = ok ? j : 0;
-            const int dm = dd < half ? dd : dd - half;
-            const int dp = dd < half ? dd + half : dd - half;
-            const float2 t = *reinterpret_cast<const float2*>(a.cs + ((long)jj * half + dm) * 2);
+            const float2 t = *reinterpret_cast<const float2*>(a.cs + ((long)dd * n + jj) * 2);
             c_[u] = t.x; s_[u] = t.y;
-            q0[u] = qb[(long)dd * n + jj]; q1[u] = qb[(long)dp * n + jj];
-            k0[u] = kb[(long)dd * n + jj]; k1[u] = kb[(long)dp * n + jj];
+            q0[u] = qb[(long)dd * n + jj]; q1[u] = qb[(long)(dd + half) * n + jj];
+            k0[u] = kb[(long)dd * n + jj]; k1[u] = kb[(long)(dd + half) * n + jj];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + tid + u * 256;
             const int d = i / npad, j = i - d * npad;
-            if (i < DK * npad) {
+            if (i < half * npad) {
                 const bool ok = j < n;
-                const float sg = d < half ? -1.0f : 1.0f;
-                qs[i] = ok ? q0[u] * c_[u] + sg * q1[u] * s_[u] : 0.0f;
-                ks[i] = ok ? k0[u] * c_[u] + sg * k1[u] * s_[u] : 0.0f;
+                qs[i] = ok ? q0[u] * c_[u] + -1.0f * q1[u] * s_[u] : 0.0f;                       // d < half
+                ks[i] = ok ? k0[u] * c_[u] + -1.0f * k1[u] * s_[u] : 0.0f;
+                qs[i + half * npad] = ok ? q1[u] * c_[u] + 1.0f * q0[u] * s_[u] : 0.0f;          // d + half
+                ks[i + half * npad] = ok ? k1[u] * c_[u] + 1.0f * k0[u] * s_[u] : 0.0f;
             }
         }
     }

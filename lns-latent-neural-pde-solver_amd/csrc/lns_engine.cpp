@@ -438,8 +438,10 @@ struct Planner {
         if (g.variant == CV_B1 && pk.Cin_pad <= 64 && g.cout_tiles >= 2 && fuse_pack < 0) {
             // input-stationary form; the number of cout tiles per block only changes the launch shape, never a bit
             static const bool off = getenv("LNS_CONV1_NO_STATIONARY") != nullptr;
+            // ... as many cout tiles per block as still leave this many blocks (three fit a CU): LNS_CONV1S_MIN_BLOCKS
+            static const long want = getenv("LNS_CONV1S_MIN_BLOCKS") ? atol(getenv("LNS_CONV1S_MIN_BLOCKS")) : 512;
             int cpb = g.cout_tiles;
-            while (cpb > 2 && (long)B * g.tiles_x * ((g.cout_tiles + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
+            while (cpb > 2 && (long)B * g.tiles_x * ((g.cout_tiles + cpb - 1) / cpb) < want) cpb = (cpb + 1) / 2;
             if (!off) a.ct_per_block = cpb;
         }
         a.bias = pk.has_bias ? as_ptr<const float>(wt(pk.b_off)) : nullptr;

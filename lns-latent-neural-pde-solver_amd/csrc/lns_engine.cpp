@@ -681,7 +681,8 @@ struct Planner {
         // InstanceNorm output (biased variance over H*W values): |y| <= sqrt(H*W - 1)
         uphi.amax = 0; uphi.amax_const = sqrtf((float)(H * W));
         TRef out;
-        if (can_fuse_1x1(e->packs[l.out1], e->packs[l.out3])) {
+        static const bool no_fuse_out = getenv("LNS_FA_NO_FUSE_TO_OUT") != nullptr;      // tuning knob (measured: fused wins)
+        if (!no_fuse_out && can_fuse_1x1(e->packs[l.out1], e->packs[l.out3])) {
             // to_out.1 (512 -> 64, GELU) and to_out.3 (64 -> 64) + skip in ONE kernel
             out = conv_same1(uphi, l.out1, ACT_GELU, &x, nullptr, l.name + ".to_out.1+3", l.out3, raw_out);
             free_t(uphi);

@@ -673,6 +673,8 @@ struct Planner {
             op.fs.ky = as_ptr<const float>(tag(SP_WS, ky_off)); op.fs.B = B; op.fs.heads = heads; op.fs.C = dh;
             op.fs.H = H; op.fs.W = W; op.fs.eps = 1e-5f; op.fs.instnorm = 1; op.fs.out = as_ptr<float>(uphi.ptr);
             op.fs.amax_u = uphi.amax ? as_ptr<const unsigned>(uphi.amax) : nullptr;
+            static const bool no_rev = getenv("LNS_FA_NO_REVERSE") != nullptr;
+            op.fs.b_rev = no_rev ? 0 : 1;
             op.flops = 2.0 * B * heads * dh * ((double)H * W * W + (double)H * H * W);
             op.bytes = 8.0 * B * heads * dh * H * W;
             plan->ops.push_back(op);
@@ -2139,7 +2141,7 @@ int lns_op_fa_sandwich(const float* u, const float* kx, const float* ky, int B, 
                        int apply_instance_norm, float* out, void* stream) {
     if (!u || !kx || !ky || !out) return LNS_EINVAL;
     OPCHK(init_kernels());
-    FaSandwichArgs a = {u, kx, ky, B, heads, C, H, W, eps, apply_instance_norm, out, nullptr};
+    FaSandwichArgs a = {u, kx, ky, B, heads, C, H, W, eps, apply_instance_norm, out, nullptr, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // max |u| per sample (what the in_proj convolution records inside a plan): enables the f16x2 form
     unsigned* damax = nullptr;

@@ -186,6 +186,7 @@ struct FaSandwichArgs {
     const float* u; const float* kx; const float* ky;
     int B, heads, C, H, W; float eps; int instnorm; float* out;
     const unsigned* amax_u;            // [B][LNS_AMAX_SUB] max |u| per sample (bit patterns) or null: enables the f16x2 form
+    int b_rev;                         // f16x2 form: walk the samples in reverse launch order (scheduling only)
 };
 hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s);
 size_t fa_sandwich_lds_bytes(int H, int W);

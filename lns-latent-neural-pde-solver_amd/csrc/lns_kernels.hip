@@ -3703,7 +3703,9 @@ __global__ __launch_bounds__(256, (WT <= 2 && (VEC || HT * WT < 4) ? 2 : 1)) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int H = a.H, W = a.W, C = a.C;
-    const int h = blockIdx.y, b = blockIdx.z;
+    // samples in REVERSE launch order (a.b_rev): the producer (in_proj) wrote sample B-1 last and the consumer (to_out) reads
+    // sample 0 first, so both hand-overs of the 537 MB tensor start on the end that is still in the Infinity Cache
+    const int h = blockIdx.y, b = a.b_rev ? a.B - 1 - (int)blockIdx.z : (int)blockIdx.z;
     const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
     const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
     float s_p, i_p, s_kx, i_kx, s_ky, i_ky, s_u, i_u;       // scales and their inverses (powers of two)

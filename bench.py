@@ -144,15 +144,22 @@ def golden_check(preset, T, out2, fixture):
     nrm = np.sqrt((out2.astype(np.float64) ** 2).sum((-1, -2)))
     tt = min(T, g["dec_norm_f64"].shape[1])
     nerr = float(np.abs(nrm[:, :tt] / g["dec_norm_f64"][:, :tt] - 1.0).max())
-    # pass: 1e-4 against the reference wherever the reference itself is reproducible to 3e-5 (north star), and within
-    # 5x / 10x of the reference's own fp32-vs-fp64 deviation further out (tests/test_gpu_parity.py, same rule)
+    # pass: 1e-4 against the reference's fp32 run wherever the reference itself is reproducible to 3e-5 (north star);
+    # further out, against the fp64 run, at most 2x the MAXIMUM over the fixture's ensemble of real-reference fp32 runs
+    # at that step while that maximum is below 1e-2 (tests/test_gpu_parity.py, same rule; tools/make_golden.py `ens`)
+    ens = g["ref_ens_err_sub"] if "ref_ens_err_sub" in g else None
     ok = True
     for r in rows:
         n = r["reference_fp32_vs_fp64"]
         if n <= 3e-5:
             ok = ok and r["rel_l2_vs_reference_fp32"] < 1e-4
-        if n <= 1e-2:
-            ok = ok and r["rel_l2_vs_reference_fp64"] <= max((5.0 if n <= 1e-4 else 10.0) * n, 2e-5)
+        if ens is not None:
+            i = meta["steps"].index(r["step"])
+            emax = float(ens[:, i].max())
+            r["reference_ensemble_max_vs_fp64"] = emax
+            r["reference_ensemble_median_vs_fp64"] = float(np.median(ens[:, i]))
+            if emax <= 1e-2:
+                ok = ok and r["rel_l2_vs_reference_fp64"] <= max(2.0 * emax, 2e-5)
     return {"fixture": fixture + ".npz", "trajectories": 2, "finite": bool(np.isfinite(out2).all()), "steps": rows,
             "max_frame_norm_rel_dev_vs_reference_fp64": nerr, "pass": bool(ok and np.isfinite(out2).all())}
 

@@ -138,6 +138,8 @@ int lns_finalize_weights(lns_engine* e, int device);
  *   "decode_streams"  decode streams of the overlapped rollout (1..4)
  *   "overlap"         1: latent chain on a side stream, decodes round-robin on the decode streams; 0: one stream
  *   "prop_priority"   1: the side stream of the latent chain is created with the highest stream priority
+ *   "track_nonfinite" 1: lns_check_finite also remembers the plan runs whose amax record has been reused since (the
+ *                     earlier steps / decode groups of a rollout): one extra one-block launch per plan run (default 0)
  * Defaults come from LNS_DECODE_GROUP / LNS_DECODE_STREAMS / LNS_NO_OVERLAP / LNS_PROP_PRIORITY at lns_create().
  * Changing an option changes the workspace size: call lns_prepare() again. */
 int lns_set_option(lns_engine* e, const char* name, long value);
@@ -178,8 +180,12 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
  * anywhere in a tensor survives in it.  This call synchronises `stream`, reads those few KB back from `workspace`
  * (the one the last lns_encode / lns_decode / lns_propagate / lns_rollout* call for batch B used) and returns
  * LNS_ENONFINITE with lns_last_error() naming the first layer (in execution order) and sample whose output was not
- * finite -- or LNS_OK.  The reference has no equivalent (its fields would silently carry NaN); nothing on the hot
- * path depends on it. */
+ * finite -- or LNS_OK.  `workspace` / B must be those of the last call (LNS_ESTATE otherwise, also after
+ * lns_finalize_weights / lns_set_option, which drop the plans the records belong to; LNS_ENOMEM if workspace_bytes
+ * does not cover the records).  Coverage: every tensor a layer wrote in the LAST RUN of each plan of that call,
+ * the plan outputs (z, y) included; earlier runs of the same plan in that call (steps < T of a rollout) only with the
+ * "track_nonfinite" option.  The reference has no equivalent (its fields would silently carry NaN); nothing on
+ * the hot path depends on it. */
 int lns_check_finite(lns_engine* e, int B, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- diagnostics -------------------------------------------------------- */

@@ -464,7 +464,9 @@ struct Planner {
             if (!in.amax && in.ss == 0) a.bound_final = 1;     // analytic bound of a raw tensor (LayerNorm / InstanceNorm output)
         }
         out.amax = 0; out.amax_const = 0.0f; out.gn_bound = 0.0f;
-        if (want_amax && !out_forced && g.variant != CV_THIN) { out.amax = new_amax(name); a.amax_out = as_ptr<unsigned>(out.amax); }
+        // a tensor written to a caller's buffer (the plan's output) is always recorded: nobody scales by it, but
+        // lns_check_finite must see a NaN born in the last layer as well
+        if ((want_amax && g.variant != CV_THIN) || out_forced) { out.amax = new_amax(name); a.amax_out = as_ptr<unsigned>(out.amax); }
         a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad; a.kc_log2 = g.sel_kc_log2;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
@@ -1066,6 +1068,7 @@ static int finalize_weights(lns_engine* e, int device) {
         for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
         m->clear();
     }
+    e->ran.clear(); e->ran_ws = nullptr; e->ran_B = 0;     // lns_check_finite has nothing to look at until the next run
     return LNS_OK;
 }
 
@@ -1098,6 +1101,7 @@ static int get_plan(lns_engine* e, PlanKind kind, int B, int H, int W, Plan** ou
     const lns_config& c = e->cfg;
     Plan plan;
     plan.B = B; plan.H = H; plan.W = W;
+    plan.kind = (int)kind; plan.key = key;
     try {
         Planner pl(e, &plan, B);
         pl.init_stat_scratch();
@@ -1155,10 +1159,19 @@ struct Runner {
             B.bs[SP_EXT0 + i] = ext[i].bs; B.bs2[SP_EXT0 + i] = ext[i].bs2; B.bdiv[SP_EXT0 + i] = ext[i].bdiv;
         }
         // the amax side channel accumulates with atomic max: every run of the plan starts from zero
-        if (plan.amax_bytes) HIPCHK(e, hipMemsetAsync(arena_base + plan.amax_off, 0, plan.amax_bytes, stream));
-        {
-            const std::pair<const Plan*, char*> key(&plan, arena_base);
-            if (std::find(e->ran.begin(), e->ran.end(), key) == e->ran.end()) e->ran.push_back(key);
+        if (plan.amax_bytes) {
+            // "track_nonfinite": what this region recorded in its PREVIOUS run (an earlier step of a rollout, another
+            // decode group) is folded into the engine's sticky word before it is zeroed
+            if (e->opt_track_nonfinite && e->d_sticky)
+                HIPCHK(e, launch_amax_sticky(reinterpret_cast<const unsigned*>(arena_base + plan.amax_off), (int)(plan.amax_bytes / 4),
+                                             e->d_sticky + plan.kind, stream));
+            HIPCHK(e, hipMemsetAsync(arena_base + plan.amax_off, 0, plan.amax_bytes, stream));
+        }
+        if (e->ran_ws) {
+            const size_t off = (size_t)(arena_base - static_cast<const char*>(e->ran_ws));
+            bool seen = false;
+            for (const auto& r : e->ran) seen = seen || (r.kind == plan.kind && r.key == plan.key && r.arena_off == off);
+            if (!seen) e->ran.push_back({plan.kind, plan.key, off});
         }
         for (const Op& op : plan.ops) {
             if (skip_step_invariant && (op.type == OP_CONDBASE || op.type == OP_CONDBLK)) continue;
@@ -1488,6 +1501,7 @@ void lns_destroy(lns_engine* e) {
     for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans})
         for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
     if (e->d_weights) (void)hipFree(e->d_weights);
+    if (e->d_sticky) (void)hipFree(e->d_sticky);
     release_overlap_objects(e);
     delete e;
 }
@@ -1534,10 +1548,12 @@ int lns_set_option(lns_engine* e, const char* name, long value) {
     if (n == "decode_group") { if (value < 0 || value > 8) return LNS_EINVAL; e->opt_decode_group = (int)value; }
     else if (n == "decode_streams") { if (value < 1 || value > NDEC) return LNS_EINVAL; e->opt_decode_streams = (int)value; }
     else if (n == "overlap") e->opt_overlap = value != 0;
+    else if (n == "track_nonfinite") e->opt_track_nonfinite = value != 0;
     else if (n == "prop_priority") {
         if (e->opt_prop_priority != (value != 0)) { DeviceGuard dg(e); release_overlap_objects(e); }   // recreated with the new priority
         e->opt_prop_priority = value != 0;
     } else { e->err = "unknown option: " + n; return LNS_EINVAL; }
+    e->ran.clear(); e->ran_ws = nullptr; e->ran_B = 0;
     return LNS_OK;
 }
 
@@ -1573,6 +1589,20 @@ static int check_ws(lns_engine* e, const WsLayout& L, void* ws, size_t bytes) {
 
 static int encode_impl(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream);
 
+// every top-level entry point: forget what the previous call ran (lns_check_finite looks at the LAST call only)
+static void begin_run(lns_engine* e, const void* ws, int B) {
+    e->ran.clear(); e->ran_ws = ws; e->ran_B = B;
+    e->sticky_armed = false;
+}
+// (called once the stream of the run is known: the sticky word is zeroed IN STREAM ORDER, in front of the run's kernels)
+static int arm_sticky(lns_engine* e, hipStream_t s) {
+    if (!e->opt_track_nonfinite) return LNS_OK;
+    if (!e->d_sticky) HIPCHK(e, hipMalloc(reinterpret_cast<void**>(&e->d_sticky), 16));
+    HIPCHK(e, hipMemsetAsync(e->d_sticky, 0, 16, s));
+    e->sticky_armed = true;
+    return LNS_OK;
+}
+
 int lns_encode(lns_engine* e, const float* x, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
     if (e && e->cfg.cond_encoder) { e->err = "this autoencoder's encoder is conditional: use lns_encode_cond(x, param)"; return LNS_EINVAL; }
     return encode_impl(e, x, nullptr, B, z, ws, ws_bytes, stream);
@@ -1598,7 +1628,8 @@ static int encode_impl(lns_engine* e, const float* x, const float* param, int B,
     ext[EX_OUT] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
     ext[EX_PARAM] = {param, 1};
     Runner r(e, static_cast<hipStream_t>(stream));
-    e->ran.clear();
+    begin_run(e, ws, B);
+    if ((rc = arm_sticky(e, r.stream))) return rc;
     if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
     return r.finish();
 }
@@ -1616,7 +1647,8 @@ int lns_decode(lns_engine* e, const float* z, int B, float* y, void* ws, size_t 
     ext[EX_IN] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
     ext[EX_OUT] = {y, (long)c.in_channels * c.Ly * c.Lx};
     Runner r(e, static_cast<hipStream_t>(stream));
-    e->ran.clear();
+    begin_run(e, ws, B);
+    if ((rc = arm_sticky(e, r.stream))) return rc;
     if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
     return r.finish();
 }
@@ -1636,7 +1668,8 @@ int lns_propagate(lns_engine* e, const float* z_in, const float* param, int B, i
     ext[EX_OUT] = {z_out, per};
     ext[EX_PARAM] = {param, 1};
     Runner r(e, static_cast<hipStream_t>(stream));
-    e->ran.clear();
+    begin_run(e, ws, B);
+    if ((rc = arm_sticky(e, r.stream))) return rc;
     if ((rc = r.run(*p, ext, static_cast<char*>(ws)))) return rc;
     return r.finish();
 }
@@ -1771,7 +1804,8 @@ int lns_rollout(lns_engine* e, const float* x, const float* param, int B, int T,
     Runner r(e, static_cast<hipStream_t>(stream));
     ExtT ext[EX_COUNT];
     ext[EX_PARAM] = {param, 1};
-    e->ran.clear();
+    begin_run(e, ws, B);
+    if ((rc = arm_sticky(e, r.stream))) return rc;
     // encode once: x -> z0                                    (train_stage2_ns2d.py:144)
     ext[EX_IN] = {x, (long)c.in_channels * c.Ly * c.Lx};
     ext[EX_OUT] = {base, zper};
@@ -1791,7 +1825,8 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
     Runner r(e, static_cast<hipStream_t>(stream));
-    e->ran.clear();
+    begin_run(e, ws, B);
+    if ((rc = arm_sticky(e, r.stream))) return rc;
     ExtT z0 = {z_in, (long)e->lat_C * e->lat_H * e->lat_W};
     if ((rc = rollout_loop(e, r, z0, param, B, T, to_x, out, nullptr, z_last, L, static_cast<char*>(ws)))) return rc;
     return r.finish();
@@ -1799,19 +1834,30 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
 
 int lns_check_finite(lns_engine* e, int B, void* ws, size_t ws_bytes, void* stream) {
     if (!e || B <= 0 || !ws) return LNS_EINVAL;
-    (void)ws_bytes;
+    // The amax vectors live in the CALLER's workspace: they are read through the `ws` handed in here, which must be
+    // the workspace (and batch) of the last run; plans are looked up again by key, so a call after
+    // lns_finalize_weights / a dropped plan reports LNS_ESTATE instead of touching freed memory.
+    if (e->ran.empty() || e->ran_ws != ws || e->ran_B != B) {
+        e->err = e->ran.empty() ? "lns_check_finite: no run to check (call it right after encode / decode / propagate / rollout)"
+                                : "lns_check_finite: the last run used a different workspace or batch";
+        return LNS_ESTATE;
+    }
     DeviceGuard dg(e);
     HIPCHK(e, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     std::vector<unsigned> host;
-    for (const auto& pr : e->ran) {                        // in the order the last call first ran them
-        const Plan& p = *pr.first;
+    for (const auto& rr : e->ran) {                        // in the order the last call first ran them
+        auto& m = rr.kind == PK_ENC ? e->enc_plans : (rr.kind == PK_DEC ? e->dec_plans : e->prop_plans);
+        auto it = m.find(rr.key);
+        if (it == m.end()) { e->err = "lns_check_finite: the plan of the last run was dropped"; return LNS_ESTATE; }
+        const Plan& p = it->second;
         if (!p.amax_bytes) continue;
+        if (rr.arena_off + p.amax_off + p.amax_bytes > ws_bytes) {
+            e->err = fmt("lns_check_finite: workspace of %zu bytes does not hold the last run's arena", ws_bytes);
+            return LNS_ENOMEM;
+        }
         host.resize(p.amax_bytes / 4);
-        HIPCHK(e, hipMemcpy(host.data(), pr.second + p.amax_off, p.amax_bytes, hipMemcpyDeviceToHost));
-        const char* what = "plan";
-        for (const auto& kv : e->enc_plans) if (&kv.second == &p) what = "encoder";
-        for (const auto& kv : e->dec_plans) if (&kv.second == &p) what = "decoder";
-        for (const auto& kv : e->prop_plans) if (&kv.second == &p) what = "propagator";
+        HIPCHK(e, hipMemcpy(host.data(), static_cast<const char*>(ws) + rr.arena_off + p.amax_off, p.amax_bytes, hipMemcpyDeviceToHost));
+        const char* what = rr.kind == PK_ENC ? "encoder" : (rr.kind == PK_DEC ? "decoder" : "propagator");
         const size_t per = (size_t)p.B * LNS_AMAX_SUB;
         for (size_t i = 0; i < p.amax_names.size(); ++i)
             for (size_t bk = 0; bk < per; ++bk)
@@ -1820,6 +1866,16 @@ int lns_check_finite(lns_engine* e, int B, void* ws, size_t ws_bytes, void* stre
                     e->err = fmt("non-finite values in the output of %s (%s, sample %d)", p.amax_names[i].c_str(), what, s % B);
                     return LNS_ENONFINITE;
                 }
+    }
+    if (e->sticky_armed && e->d_sticky) {                  // runs whose amax region has been reused since (earlier steps / groups)
+        unsigned st[4] = {0, 0, 0, 0};
+        HIPCHK(e, hipMemcpy(st, e->d_sticky, 16, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; ++k)
+            if (st[k]) {
+                e->err = fmt("non-finite values in an earlier %s run of the last call (its amax record has been reused since)",
+                             k == PK_ENC ? "encoder" : (k == PK_DEC ? "decoder" : "propagator"));
+                return LNS_ENONFINITE;
+            }
     }
     return LNS_OK;
 }
@@ -1872,7 +1928,7 @@ struct OpConv {
 static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, int Win, int Hv, int Wv,
                            const float* w_host, const float* bias_host, int Cout, int ksize, int stride, int dilation,
                            int pad_t, int pad_b, int pad_l, int pad_r, int mode_y, int mode_x, const float* ss, int act_in,
-                           int act_out, const float* residual, const float* badd, float* y, int tile_variant) {
+                           int act_out, const float* residual, const float* badd, float* y, int tile_variant, hipStream_t stream) {
     if (!x || !w_host || !y || (ksize != 1 && ksize != 3)) return LNS_EINVAL;
     if (act_in != ACT_NONE && act_in != ACT_SWISH) return LNS_EINVAL;   // prologue: GroupNorm scale/shift + Swish only
     OPCHK(init_kernels());
@@ -1935,9 +1991,10 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.unscale = (cv_is_f16x2_3x3(g.variant) || g.variant == CV_B1) ? 1.0f / wscale : 1.0f;
     // the input's per-sample maximum, as the producing kernel of a plan would have recorded it
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.damax), (size_t)B * LNS_AMAX_SUB * 4));
-    OPCHK(hipMemset(oc.damax, 0, (size_t)B * LNS_AMAX_SUB * 4));
-    OPCHK(launch_amax(x, a.x_bs, (long)Cin * Hin * Win, B, oc.damax, nullptr));
-    OPCHK(hipStreamSynchronize(nullptr));
+    // (on the CALLER's stream: x may still be being produced there, and a non-blocking stream does not order with the
+    //  null stream -- a maximum taken too early would give a scale that overflows fp16)
+    OPCHK(hipMemsetAsync(oc.damax, 0, (size_t)B * LNS_AMAX_SUB * 4, stream));
+    OPCHK(launch_amax(x, a.x_bs, (long)Cin * Hin * Win, B, oc.damax, stream));
     a.amax_in = oc.damax;
     a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
@@ -1956,9 +2013,10 @@ int lns_op_conv2d(const float* x, int B, int Cin, int Hin, int Win, int Hv, int 
                   const float* badd, float* y, int tile_variant, void* stream, unsigned* amax_out) {
     OpConv oc;
     const int rc = op_conv_prepare(oc, x, B, Cin, Hin, Win, Hv, Wv, w_host, bias_host, Cout, ksize, stride, dilation, pad_t,
-                                   pad_b, pad_l, pad_r, mode_y, mode_x, ss, act_in, act_out, residual, badd, y, tile_variant);
+                                   pad_b, pad_l, pad_r, mode_y, mode_x, ss, act_in, act_out, residual, badd, y, tile_variant,
+                                   static_cast<hipStream_t>(stream));
     if (rc) { oc.release(); return rc; }
-    oc.a.amax_out = oc.variant == CV_THIN ? nullptr : amax_out;   // the thin final projection records none
+    oc.a.amax_out = amax_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #ifdef LNS_TS
     // diagnostic build: per-block phase timestamps of the split-operand 3x3 kernel, appended to $LNS_TS_FILE
@@ -2022,7 +2080,7 @@ int lns_op_conv_pair_stress(int B, int H, int W, int cin_a, int cout_a, int ksiz
         OPCHK(hipMemcpy(s.ss, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
         const int p = ks[i] / 2;
         const int rc = op_conv_prepare(s.oc, s.x, B, cin[i], H, W, H, W, hw.data(), nullptr, cout[i], ks[i], 1, 1, p, p, p, p,
-                                       1, 1, s.ss, ACT_SWISH, ACT_NONE, nullptr, nullptr, s.y, var[i]);
+                                       1, 1, s.ss, ACT_SWISH, ACT_NONE, nullptr, nullptr, s.y, var[i], st[i]);
         if (rc) return rc;
         s.ref.resize(s.ny); s.out.resize(s.ny);
         OPCHK(launch_conv(s.oc.variant, s.oc.a, st[i]));

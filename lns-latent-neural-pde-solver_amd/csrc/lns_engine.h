@@ -108,6 +108,7 @@ struct Plan {
     void* d_consts = nullptr;         // device: ints then floats
     size_t arena_bytes = 0;
     int B = 0, H = 0, W = 0;
+    int kind = 0; long key = 0;       // which cache holds this plan, under which key
     // amax side channel (dynamic activation scale of the split-operand convs): [slots][B] unsigned inside the arena,
     // zeroed by one memset at the start of every run of the plan; slot i belongs to the tensor amax_names[i]
     size_t amax_off = 0, amax_bytes = 0;
@@ -148,8 +149,18 @@ struct lns_engine {
     int opt_decode_streams = 3;
     int opt_overlap = 1;           // propagator / decode streams; 0 = everything on the caller's stream
     int opt_prop_priority = 0;     // 1: the propagator's side stream is created with the highest priority
-    // (plan, arena) pairs the last top-level call ran: lns_check_finite reads their amax vectors
-    std::vector<std::pair<const lns::Plan*, char*>> ran;
+    // what the last top-level call ran, for lns_check_finite: (plan kind, plan key, arena offset inside the caller's
+    // workspace) -- no pointers into the plan caches or the workspace, which the caller may drop at any time -- plus
+    // the workspace and batch of that call.  Cleared whenever plans are dropped.
+    struct RanRec { int kind; long key; size_t arena_off; };
+    std::vector<RanRec> ran;
+    const void* ran_ws = nullptr;
+    int ran_B = 0;
+    // "track_nonfinite" option: a device word per plan kind that remembers a non-finite amax record of ANY plan run of
+    // the last call (one extra 1-block launch per plan run; off by default)
+    int opt_track_nonfinite = 0;
+    unsigned* d_sticky = nullptr;
+    bool sticky_armed = false;
     // diagnostics
     bool trace_on = false;
     std::vector<lns::TraceRec> trace;

@@ -83,8 +83,11 @@ enum ConvVariant { CV_L128 = 0, CV_L64 = 1, CV_M128 = 2, CV_M64 = 3, CV_S64 = 4,
                    CV_F64 = 11 /* 3x3 kernel with the two-term fp16 split (f16x2), 64 couts x 128 pixels */,
                    CV_THIN = 12 /* streaming 1x1 projection to <= 4 output channels (VALU, HBM-bound) */,
                    CV_F32 = 13 /* f16x2 3x3 kernel, 32 couts x 128 pixels (same bits as CV_F64) */,
-                   CV_F256 = 14 /* f16x2 3x3 kernel, 64 couts x 256 pixels: a wave owns 64 couts x 64 pixels (same bits as CV_F64) */ };
-inline bool cv_is_f16x2_3x3(int v) { return v == CV_F64 || v == CV_F32 || v == CV_F256; }
+                   CV_F256 = 14 /* f16x2 3x3 kernel, 64 couts x 256 pixels: a wave owns 64 couts x 64 pixels (same bits as CV_F64) */,
+                   // f16x2 3x3 kernel with producer / consumer wave specialisation (conv3_pc.inc; same bits as CV_F64):
+                   CV_P128 = 15 /* 64 couts x 128 pixels per 512-thread block */, CV_P256 = 16 /* 64 couts x 256 pixels */ };
+inline bool cv_is_pc(int v) { return v == CV_P128 || v == CV_P256; }
+inline bool cv_is_f16x2_3x3(int v) { return v == CV_F64 || v == CV_F32 || v == CV_F256 || cv_is_pc(v); }
 inline bool cv_is_split_3x3(int v) { return v == CV_B64 || v == CV_B32 || cv_is_f16x2_3x3(v); }
 struct ConvVariantInfo { int TM, TN; };
 ConvVariantInfo conv_variant_info(int v);
@@ -103,6 +106,11 @@ hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s);
 size_t convb_lds_bytes(const ConvArgs& a, int tile_couts, int splits, int ring);
 bool convb_fits(const ConvArgs& a);
 hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s);
+// producer / consumer form (nt = 1: 128-pixel tiles, 2: 256-pixel tiles); one 512-thread block per CU walks several tiles
+size_t convpc_lds_bytes(const ConvArgs& a, int nt);
+bool convpc_geom_fits(const ConvArgs& a, int nt);     // patch / LDS only (planning time: pointers and strides unknown)
+bool convpc_fits(const ConvArgs& a, int nt);
+hipError_t launch_conv_pc(int nt, const ConvArgs& a, hipStream_t s);
 // host-side packing of one [Cout][Cin][3][3] weight (cout offset co0 inside the pack) into the bf16x3 slab layout
 size_t convb_weight_bytes(int Cout, int Cin_pad);
 void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);
@@ -252,6 +260,7 @@ hipError_t launch_metric_rel_l2_ch(const float* yhat, const float* y, int B, int
 
 // per-sample max |x| (bit patterns) of a [B, n] tensor with batch stride x_bs into amax [B][LNS_AMAX_SUB] (atomic max)
 hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax, hipStream_t s);
+hipError_t launch_amax_sticky(const unsigned* amax, int n, unsigned* flag, hipStream_t s);
 
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
 

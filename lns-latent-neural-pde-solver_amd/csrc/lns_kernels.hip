@@ -124,6 +124,10 @@ __device__ __forceinline__ void amax_publish_block(unsigned* amax, int b, unsign
 // S = 2^(CONVF_TARGET_EXP - e) for bound = m 2^e (1 <= m < 2), clamped to [2^-110, 2^120]; inv = 1 / S.
 // Non-finite bound (exponent field 255): S = 2^-110 and the staged values stay non-finite -> NaN results, as in fp32.
 __device__ __forceinline__ float f16x2_scale(unsigned bound_bits, float& inv) {
+#ifdef LNS_FIXED_ACT_SCALE      // attribution builds only (tools/drift_attribution.sh): round 1's constant activation scale
+    inv = 1.0f / (float)(LNS_FIXED_ACT_SCALE);
+    return (float)(LNS_FIXED_ACT_SCALE);
+#endif
     const int eb = (int)((bound_bits >> 23) & 0xffu);
     int f = 127 + CONVF_TARGET_EXP + 127 - eb;
     f = f < 17 ? 17 : (f > 247 ? 247 : f);
@@ -595,7 +599,7 @@ static const ConvVariantInfo kConvInfo[CV_COUNT] = {
 
 ConvVariantInfo conv_variant_info(int v) {
     return (v == CV_B32 || v == CV_F32) ? ConvVariantInfo{32, 128} : v == CV_THIN ? ConvVariantInfo{32, 1024}
-           : v == CV_F256 ? ConvVariantInfo{64, 256} : v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v];
+           : (v == CV_F256 || v == CV_P256) ? ConvVariantInfo{64, 256} : v >= CV_B64 ? ConvVariantInfo{64, 128} : kConvInfo[v];
 }
 
 // Stage depth (channels per LDS stage).  It is a function of the kernel size ONLY
@@ -612,6 +616,7 @@ int conv_pick_kc_log2(int ks, int stride, int kc_log2_max) {
 static int conv_maxe(int ks, int KC) { return ks == 3 ? (KC == 8 ? CONV_MAXE3_K8 : CONV_MAXE3) : CONV_MAXE1; }
 
 size_t conv_lds_bytes(int variant, const ConvArgs& a) {
+    if (cv_is_pc(variant)) return convpc_lds_bytes(a, variant == CV_P256 ? 2 : 1);
     if (cv_is_split_3x3(variant))
         return convb_lds_bytes(a, (variant == CV_B32 || variant == CV_F32) ? 32 : 64, cv_is_f16x2_3x3(variant) ? 2 : 3, 2);
     if (variant == CV_B1) return convb1_lds_bytes(a);
@@ -624,6 +629,7 @@ size_t conv_lds_bytes(int variant, const ConvArgs& a) {
 }
 
 bool conv_fits(int variant, const ConvArgs& a) {
+    if (cv_is_pc(variant)) return convpc_geom_fits(a, variant == CV_P256 ? 2 : 1);
     if (cv_is_split_3x3(variant)) return convb_fits(a);
     if (variant == CV_B1) return convb1_fits(a);
     if (variant == CV_THIN) return a.ks == 1 && a.stride == 1;   // pointer-dependent conditions are checked at launch
@@ -658,6 +664,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 }
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
+    if (cv_is_pc(variant)) return launch_conv_pc(variant == CV_P256 ? 2 : 1, a, s);
     if (cv_is_split_3x3(variant)) return launch_conv_bf16x3(variant, a, s);
     if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
     if (variant == CV_THIN) return launch_conv1_thin(a, s);
@@ -2121,6 +2128,8 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#include "conv3_pc.inc"
+
 // ===========================================================================
 // Thin 1x1 projection (<= 4 output channels, e.g. the decoder's last 64 -> 3 conv): pure streaming, no matrix pipe.
 // A thread owns 4 consecutive pixels and walks the input channels with 16-byte loads (8 in flight), applying the
@@ -2140,8 +2149,9 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
     for (int i = tid; i < C; i += 256)
         ssm[i] = has_ss ? make_float2(a.ss[((long)b * C + i) * 2], a.ss[((long)b * C + i) * 2 + 1]) : make_float2(1.0f, 0.0f);
     __syncthreads();
-    const int p4 = blockIdx.x * 256 + tid;                        // group of 4 pixels
-    if (p4 * 4 >= HW) return;
+    const int p4r = blockIdx.x * 256 + tid;                       // group of 4 pixels
+    const bool live = p4r * 4 < HW;                               // (a thread past the plane redoes group 0 and stores nothing)
+    const int p4 = live ? p4r : 0;
     const float* xb = a.x + (long)b * a.x_bs + (long)p4 * 4;
     const bool swish = has_ss && a.act_in == ACT_SWISH;
     float acc[4][4];
@@ -2180,16 +2190,24 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
     float bv[4];                                               // bias loads ahead of the stores
 #pragma unroll
     for (int co = 0; co < 4; ++co) bv[co] = a.bias ? a.bias[co < CO ? co : 0] : 0.0f;
+    unsigned am = 0u;
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
-        if (co < CO)
-            *reinterpret_cast<float4*>(yb + (long)co * HW) = make_float4(acc[co][0] + bv[co], acc[co][1] + bv[co], acc[co][2] + bv[co], acc[co][3] + bv[co]);
+        if (co < CO && live) {
+            const float4 o = make_float4(acc[co][0] + bv[co], acc[co][1] + bv[co], acc[co][2] + bv[co], acc[co][3] + bv[co]);
+            *reinterpret_cast<float4*>(yb + (long)co * HW) = o;
+            am = max(max(am, abs_bits(o.x)), max(max(abs_bits(o.y), abs_bits(o.z)), abs_bits(o.w)));
+        }
+    }
+    if (a.amax_out) {                                          // uniform; one atomic per wave (16 blocks x 4 per 128^2 sample)
+        const unsigned m = wave_umax(am);
+        if ((tid & 63) == 0 && m) atomicMax(a.amax_out + (long)b * LNS_AMAX_SUB + ((blockIdx.x * 4 + (tid >> 6)) & (LNS_AMAX_SUB - 1)), m);
     }
 }
 
 bool conv1_thin_fits(const ConvArgs& a) {
     return a.ks == 1 && a.stride == 1 && a.Cout <= 4 && a.Cin <= 512 && ((a.Hin * a.Win) % 4) == 0 && !a.res && !a.badd &&
-           a.act_out == ACT_NONE && !a.w2 && !a.amax_out && (a.act_in == ACT_NONE || a.act_in == ACT_SWISH) && (a.x_bs % 4) == 0 &&
+           a.act_out == ACT_NONE && !a.w2 && (a.act_in == ACT_NONE || a.act_in == ACT_SWISH) && (a.x_bs % 4) == 0 &&
            (a.y_bs % 4) == 0 && (a.y_bs2 % 4) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y)) & 15) == 0;
 }
 
@@ -4424,12 +4442,28 @@ hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax,
     return hipGetLastError();
 }
 
+// OR "some amax word of the region holds a non-finite bit pattern" into *flag (lns_check_finite's memory of the runs
+// whose amax region has been zeroed again since); launched in front of the region's memset when tracking is on
+__global__ __launch_bounds__(256) void amax_sticky_kernel(const unsigned* amax, int n, unsigned* flag) {
+    bool bad = false;
+    for (int i = threadIdx.x; i < n; i += 256) bad = bad || ((amax[i] >> 23) & 0xffu) == 0xffu;
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+hipError_t launch_amax_sticky(const unsigned* amax, int n, unsigned* flag, hipStream_t s) {
+    hipLaunchKernelGGL(amax_sticky_kernel, dim3(1), dim3(256), 0, s, amax, n, flag);
+    return hipGetLastError();
+}
+
 hipError_t init_kernels() {
     hipError_t e;
     const int maxlds = 160 * 1024;
 #define LNS_SET_LDS(k)                                                                            \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
+    LNS_SET_LDS((conv3_pc_kernel<1, 1>))
+    LNS_SET_LDS((conv3_pc_kernel<1, 2>))
+    LNS_SET_LDS((conv3_pc_kernel<2, 1>))
+    LNS_SET_LDS((conv3_pc_kernel<2, 2>))
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false, 4>))
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false, 8>))
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, true, 16>))

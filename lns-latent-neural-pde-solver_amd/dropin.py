@@ -24,7 +24,52 @@ from ._lib import (LNS_AE_HALF_PERIODIC, LNS_AE_NONE, LNS_AE_NONSQUARED, LNS_AE_
                    LNS_PROP_PLAIN, LnsError)
 
 
-class _Node(nn.Module):
+# Bumped whenever a drop-in module's parameter TREE may have changed identity: a Parameter / buffer object replaced
+# (`mod.x.weight = nn.Parameter(...)`, `load_state_dict(assign=True)`, `.to()` / `.cuda()` / `.float()`, which always
+# rebind buffers).  `_Hosted._engine` caches the flat (key, tensor) list and re-walks the tree when the epoch moved;
+# in-place changes (optimizer steps, `load_state_dict`, `copy_`) are caught by (storage pointer, version) per tensor.
+_TREE_EPOCH = [0]
+
+
+class _TreeWatch(nn.Module):
+    """Mix-in of every drop-in module: any rebinding of a tensor / sub-module invalidates the cached flat list."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, nn.Module)) or name in self.__dict__.get("_parameters", ()) or \
+                name in self.__dict__.get("_buffers", ()):
+            _TREE_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _TREE_EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        _TREE_EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        _TREE_EPOCH[0] += 1
+        super().register_buffer(name, tensor, persistent=persistent)
+
+    def _apply(self, fn, *a, **k):
+        _TREE_EPOCH[0] += 1
+        r = super()._apply(fn, *a, **k)
+        _TREE_EPOCH[0] += 1
+        return r
+
+    def load_state_dict(self, *a, **k):
+        _TREE_EPOCH[0] += 1
+        r = super().load_state_dict(*a, **k)
+        _TREE_EPOCH[0] += 1
+        return r
+
+    def _load_from_state_dict(self, *a, **k):      # the per-module step of a PARENT's load_state_dict(assign=True)
+        super()._load_from_state_dict(*a, **k)
+        _TREE_EPOCH[0] += 1
+
+
+class _Node(_TreeWatch):
     """Parameter container mirroring one reference sub-module."""
 
     def forward(self, *a, **k):
@@ -82,7 +127,7 @@ def _grow_tree(root, table, strip=""):
             node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
 
 
-class _Hosted(nn.Module):
+class _Hosted(_TreeWatch):
     """A module whose forward runs on an lns engine.  The engine belongs to the
     outermost constructed object (`_owner`); nested views share it."""
 
@@ -93,10 +138,21 @@ class _Hosted(nn.Module):
             object.__setattr__(self, "_eng", _engine.Engine(cfg))
             object.__setattr__(self, "_sig", None)
             object.__setattr__(self, "_flat", None)
+            object.__setattr__(self, "_flat_epoch", -1)
 
     @property
     def _owner(self):
         return self._owner_ref
+
+    def _weights_signature(self):
+        """(flat [(key, tensor)] list of the owner's CURRENT parameter tree, hashable signature of its contents)."""
+        own = self._owner
+        flat = own._flat
+        if flat is None or own._flat_epoch != _TREE_EPOCH[0]:
+            flat = [(k, t) for k, t in list(own.named_parameters()) + list(own.named_buffers())]
+            object.__setattr__(own, "_flat", flat)
+            object.__setattr__(own, "_flat_epoch", _TREE_EPOCH[0])
+        return flat, tuple((id(t), t.data_ptr(), t._version) for _, t in flat)
 
     def _engine(self, like):
         """Engine with the current weights resident on `like`'s device."""
@@ -105,15 +161,12 @@ class _Hosted(nn.Module):
             raise LnsError("the LNS drop-in runs on HIP device tensors only (input is on %s); there is "
                            "no CPU fallback -- use the reference implementation on CPU"
                            % (getattr(like, "device", "host")))
-        # The tensors of the parameter tree are looked up ONCE (the tree is fixed after construction; load_state_dict,
-        # .to(), in-place updates keep the Parameter objects and change their storage / version counter); a call only
-        # compares (storage pointer, version) of each and re-packs the weights when something changed.
-        flat = own._flat
-        if flat is None:
-            flat = [(k, t) for k, t in list(own.named_parameters()) + list(own.named_buffers())]
-            object.__setattr__(own, "_flat", flat)
+        # The tensors of the parameter tree are looked up once per TREE EPOCH (the walk costs 0.5 ms; anything that can
+        # replace a Parameter / buffer object bumps _TREE_EPOCH, see _TreeWatch); a call compares (object identity,
+        # storage pointer, version) of each tensor and re-packs the weights when something changed.
+        flat, wsig = own._weights_signature()
         dev = like.device.index if like.device.index is not None else torch.cuda.current_device()
-        sig = (dev, tuple((t.data_ptr(), t._version) for _, t in flat))
+        sig = (dev, wsig)
         if own._sig != sig:
             own._eng.load_weights({k: t.detach().to("cpu", torch.float32).numpy() for k, t in flat}, dev)
             object.__setattr__(own, "_sig", sig)

@@ -167,7 +167,7 @@ class Engine:
 
     def set_option(self, name, value):
         """Scheduling options of the rollout (include/lns.h lns_set_option): decode_group, decode_streams, overlap,
-        prop_priority.  Results never depend on them."""
+        prop_priority, track_nonfinite.  Results never depend on them."""
         self._check(self._L.lns_set_option(self._h, name.encode(), int(value)), "lns_set_option")
         self._ws.clear()                      # the workspace size depends on the options
 
@@ -301,13 +301,21 @@ class Engine:
                                                ws.data_ptr(), ws.numel(), self._stream(z)), "lns_rollout_latent")
         return out, z_last
 
-    def check_finite(self, B, device):
-        """Raises LnsError naming the first layer / sample whose output of the LAST run for batch B held inf or NaN
-        (synchronises the device's current stream; reads a few KB of the workspace back)."""
+    def check_finite(self, B, device=None):
+        """Raises LnsError naming the first layer / sample whose output held inf or NaN in the LAST call (encode /
+        decode / propagate / rollout) for batch B.  Coverage: every tensor a layer of that call wrote, including
+        the plan outputs; for a rollout the amax records are per plan RUN, so what is seen is the last propagator
+        step and the last decode on each decode stream -- `set_option("track_nonfinite", 1)` adds a sticky word that
+        also remembers the earlier steps / decode groups (one tiny extra launch per plan run).
+        Synchronises the device's current stream; reads a few KB of the workspace back."""
         import torch
-        ws = self._ws.get((B, torch.device(device)))
+        dev = torch.device("cuda" if device is None else device)
+        if dev.type != "cuda":
+            raise LnsError("check_finite: %s is not a HIP device" % (dev,))
+        dev = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        ws = self._ws.get((B, dev))
         if ws is None:
-            raise LnsError("no run for batch %d on %s yet" % (B, device))
+            raise LnsError("no run for batch %d on %s yet" % (B, dev))
         stream = ctypes.c_void_p(torch.cuda.current_stream(ws.device).cuda_stream)
         self._check(self._L.lns_check_finite(self._h, int(B), ws.data_ptr(), ws.numel(), stream), "lns_check_finite")
 

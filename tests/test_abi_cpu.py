@@ -65,6 +65,43 @@ def test_dropin_state_dict_and_cpu_refusal():
     assert "no CPU fallback" in str(ei.value)
 
 
+def test_dropin_sees_replaced_tensors():
+    """the drop-in caches the flat (key, tensor) list of its parameter tree; anything that REPLACES tensor
+    objects (load_state_dict(assign=True), `mod.w = nn.Parameter(...)`, `.to()` which rebinds buffers before a later
+    load_state_dict) must refresh it, or the engine keeps running stale weights."""
+    import torch
+    import torch.nn as nn
+    from lns_amd import config, dropin
+    m = dropin.build_dynamics(config.preset("ns2d_mini"))
+
+    def current():
+        flat, sig = m._weights_signature()
+        return dict(flat), sig
+    _, s0 = current()
+    assert current()[1] == s0                                   # stable without changes
+    sd = {k: v.clone() + 1 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)
+    cur, s1 = current()
+    assert s1 != s0 and all(torch.equal(cur[k], sd[k]) for k in sd)
+    m.double().float()                                          # Module._apply rebinds every buffer
+    _, s2 = current()
+    m.load_state_dict({k: v + 1 for k, v in sd.items()})        # ... and this copies into the NEW buffers
+    cur, s3 = current()
+    assert s3 != s2 and all(torch.equal(cur[k], sd[k] + 1) for k in sd)
+    name, p0 = next(iter(m.named_parameters()))
+    node = m
+    for part in name.split(".")[:-1]:
+        node = getattr(node, part)
+    setattr(node, name.rsplit(".", 1)[-1], nn.Parameter(p0.detach() * 2, requires_grad=False))
+    cur, s4 = current()
+    assert s4 != s3 and torch.equal(cur[name], p0 * 2)
+    with torch.no_grad():
+        cur[name].add_(1.0)                                     # in place: version counter
+    assert current()[1] != s4
+    # a nested view (model.vq_ae) shares the owner's signature
+    assert m.vq_ae._weights_signature()[1] == current()[1]
+
+
 def test_bad_config_is_an_error_not_a_crash():
     from lns_amd import config, engine, _lib
     args = config.preset("ns2d_mini", latent_resolution=8)   # violates the log2 assert of autoencoder2d.py:26
@@ -83,6 +120,7 @@ def test_device_code_has_no_packed_fp32_arithmetic():
     from lns_amd import _lib
     text = check_isa.disassemble(_lib.LIB_PATH)
     assert check_isa.count(text, r"v_pk_(fma|mul|add)_f32") == 0
+    assert check_isa.count(text, r"v_pk_mov_b32") == 0          # the same op_sel cross-half read
     assert check_isa.count(text, r"v_mfma_f32_32x32x16_f16") > 100
     assert check_isa.count(text, r"v_mfma_f32_32x32x16_bf16") > 100
     assert check_isa.count(text, r"v_mfma_f32_32x32x2_f32") > 100

@@ -48,7 +48,8 @@ def test_conv_kernel(idx, case):
 
 def test_conv_tile_variants_same_bits():
     """The f16x2 3x3 kernel accumulates every output element in the same order whatever the block tile: 64 couts x 128
-    pixels (11), 32 x 128 (13) and 64 x 256 (14) agree bit for bit -- full tiles, ragged edges and a ragged cout tile."""
+    pixels (11), 32 x 128 (13) and 64 x 256 (14) agree bit for bit -- full tiles, ragged edges and a ragged cout tile;
+    so do the producer / consumer forms (15: 128-pixel tiles, 16: 256-pixel tiles; one or several tiles per block)."""
     _need_gpu()
     import gpu_checks as gc
     import numpy as np
@@ -57,6 +58,14 @@ def test_conv_tile_variants_same_bits():
                dict(B=2, Cin=64, Cout=128, H=28, W=60, up=(61, 121), mode=(0, 0))):
         ys = [gc.conv_case(k=3, variant=v, seed=5, ret_y=True, **kw)[2] for v in (11, 13, 14)]
         assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2]), kw
+    for kw in (dict(B=2, Cin=64, Cout=64, H=32, W=32, ss=True, act_in=1, res=True),
+               dict(B=2, Cin=72, Cout=100, H=20, W=36, ss=True, act_in=1, badd=True, mode=(0, 0)),
+               dict(B=2, Cin=64, Cout=128, H=30, W=60, up=(60, 120), mode=(0, 1), act_out=2),
+               dict(B=2, Cin=128, Cout=128, H=16, W=16, dil=2, ss=True, act_in=1, act_out=2, mode=(1, 1)),
+               dict(B=5, Cin=64, Cout=128, H=64, W=64, ss=True, act_in=1, res=True, mode=(1, 1))):
+        ys = [gc.conv_case(k=3, variant=v, seed=6, ret_y=True, **kw)[2] for v in (11, 15, 16)]
+        assert np.array_equal(ys[0], ys[1]), ("variant 15", kw)
+        assert np.array_equal(ys[0], ys[2]), ("variant 16", kw)
 
 
 def _domain_cases():
@@ -201,18 +210,19 @@ def test_rollout_matches_reference_golden(case):
 
 
 # Long horizons of BASELINE configs 3 / 4 / 5 (T = 64 / 128 / 256).  The random-init dynamics amplify rounding noise
-# exponentially: the reference's OWN fp32 run is off its fp64 run by `ref_self_err[t]` (stored in the fixture;
-# 2.6e-4 @256 for NS2d, 1.8e-3 @64 for SW-5ch, O(1) beyond t ~ 90 for the conditional two-phase model), so at these
-# horizons 1e-4 against the fp32 run is not a property any two fp32 implementations share, and the reference's
-# deviation is ONE draw of that amplified noise.  Measured on MI355X against the same fp64 run (DESIGN.md section 6,
-# gpurun_out/r2_diag_*.log): the engine on exact-fp32 MFMA products is 2.8x the reference's deviation at NS2d t=128 and
-# 10.8x at t=256, on bf16x3 3.6x / 13x, on the default f16x2 1.15x / 3.7x, the round-1 build 0.43x / 1.2x.
-# Stated tolerance per horizon, against the reference's fp64 run: at most 5x the reference's own deviation (floor
-# 2e-5) while that deviation is below 1e-4, at most 10x while it is below 1e-2 (linearised regime); the 1e-4 gate
-# against the fp32 run applies wherever the reference's deviation is below 3e-5; later steps are reported, not gated
-# (chaotic regime: both runs have left the fp64 trajectory).
+# exponentially, so ONE fp32 run of the reference says little about how far a correct fp32 implementation may sit
+# from the fp64 trajectory.  The fixtures therefore hold an ENSEMBLE of the REAL reference's fp32 runs
+# (tools/make_golden.py `ens`: 8 / 1 threads, oneDNN / ATen convolutions, the input moved by +-1 ulp per element --
+# ten members, each a valid fp32 evaluation of the same model) as rel-L2 to the reference's fp64 run per step
+# (`ref_ens_err_sub`, computed on the same sub-sampled fields as the engine's distance below).  Measured spread at
+# NS2d t=256: 1.5e-4 ... 1.6e-3 (x10 between members), SW-5ch t=64: 7e-4 ... 2.2e-3.
+# Gate, against the reference's fp64 run: at most 2x the ensemble's MAXIMUM at that step (floor 2e-5) wherever that
+# maximum is below 1e-2 (linearised regime); the north star's 1e-4 against the reference's fp32 run applies wherever
+# the reference itself is reproducible to 3e-5; later steps are reported, not gated (chaotic regime: every member has
+# left the fp64 trajectory).
 LONG_CASES = ["sw_96x192x5_T64", "twophase_cond_T128", "ns2d_128_T256"]
 LINEAR_REGIME = 1e-2
+ENSEMBLE_FACTOR = 2.0
 
 
 @pytest.mark.parametrize("case", LONG_CASES)
@@ -232,21 +242,24 @@ def test_long_horizon_rollout_vs_reference(case):
     dec = dec.cpu().numpy()
     sub = meta["sub"]
     noise = g["ref_self_err"]
+    ens = g["ref_ens_err_sub"]                      # [members, stored steps]
+    assert ens.shape[0] >= 8
     report, gated = [], 0
     for i, s in enumerate(meta["steps"]):
         f = dec[:, s - 1][..., ::sub, ::sub]
-        e_dec, e64, n = rel_l2(f, g["dec"][:, i]), rel_l2(f, g["dec_f64"][:, i]), float(noise[s - 1])
-        report.append((s, e_dec, e64, n))
-        if n <= LINEAR_REGIME:
+        e_dec, e64 = rel_l2(f, g["dec"][:, i]), rel_l2(f, g["dec_f64"][:, i])
+        emax, emed = float(ens[:, i].max()), float(np.median(ens[:, i]))
+        report.append((s, e_dec, e64, emed, emax))
+        if emax <= LINEAR_REGIME:
             gated += 1
-            assert e64 <= max((5.0 if n <= 1e-4 else 10.0) * n, 2e-5), report
-        if n <= 3e-5:
+            assert e64 <= max(ENSEMBLE_FACTOR * emax, 2e-5), report
+        if float(noise[s - 1]) <= 3e-5:
             assert e_dec < ROLLOUT_TOL, report
-    print(case, report)
+    print(case, "(step, vs fp32 run, vs fp64 run, ensemble median, ensemble max)", report)
     assert gated >= 2, report
-    # per-frame norms over the whole horizon, where the reference itself is reproducible
+    # per-frame norms over the whole horizon, where every member of the ensemble is reproducible
     nrm = np.sqrt((dec.astype(np.float64) ** 2).sum((-1, -2)))
-    ok = noise <= 1e-4
+    ok = g["ref_ens_err"].max(0) <= 1e-4
     np.testing.assert_allclose(nrm[:, ok], g["dec_norm_f64"][:, ok], rtol=1e-3)
 
 
@@ -322,6 +335,86 @@ def test_check_finite_names_the_layer():
         eng.check_finite(3, xb.device)
     assert torch.isfinite(y[:2]).all() and not torch.isfinite(y[2]).all()
     assert torch.equal(y[:2], model.predict(xd, 3, to_x=True)[:2])       # the clean samples are untouched, bit for bit
+
+
+def test_check_finite_state_and_coverage():
+    """lns_check_finite resolves the last run's records through the workspace handed in (never through
+    remembered plan / arena pointers), refuses a stale or foreign workspace with LNS_ESTATE, accepts 'cuda' for
+    'cuda:0', and sees a NaN born in the LAST layer of a plan (the plan outputs record an amax too, the thin final
+    projection included); "track_nonfinite" changes no bit."""
+    _need_gpu()
+    import ctypes
+    import gpu_checks as gc
+    from lns_amd import config, filler, _lib
+    from lns_amd._lib import LnsError
+    args = config.preset("ns2d_mini")
+    from helpers import synthetic_state_dict
+    model, _ = gc.build_models(args, 1)
+    sd = synthetic_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 1)
+    x = filler.normal("x", (3, args.in_channels, args.Ly, args.Lx), 7)
+    xd = torch.from_numpy(x).cuda()
+    eng = model._engine(xd)
+    y0 = model.predict(xd, 3, to_x=True)
+    eng.check_finite(3, "cuda")                                  # torch.device('cuda') != torch.device('cuda:0')
+    eng.check_finite(3)
+    ws = eng._ws[(3, xd.device)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = eng._L
+    other = torch.empty_like(ws)
+    assert L.lns_check_finite(eng._h, 3, other.data_ptr(), other.numel(), stream) == _lib.LNS_ESTATE    # foreign workspace
+    assert L.lns_check_finite(eng._h, 2, ws.data_ptr(), ws.numel(), stream) == _lib.LNS_ESTATE          # other batch
+    assert L.lns_check_finite(eng._h, 3, ws.data_ptr(), 64, stream) == _lib.LNS_ENOMEM                  # records not covered
+    assert L.lns_check_finite(eng._h, 3, ws.data_ptr(), ws.numel(), stream) == _lib.LNS_OK
+    # lns_finalize_weights drops the plans: the records of the last run are gone with them (was: use after free)
+    eng.load_weights({k: t.detach().cpu().numpy() for k, t in model.state_dict().items()}, xd.device.index)
+    assert L.lns_check_finite(eng._h, 3, ws.data_ptr(), ws.numel(), stream) == _lib.LNS_ESTATE
+    assert b"no run" in L.lns_last_error(eng._h)
+    # a NaN born in the very last layer of the decoder (its bias): the plan output is recorded
+    last = sorted((k for k in sd if k.startswith("vq_ae.decoder.model.") and k.endswith(".bias")),
+                  key=lambda k: int(k.split(".")[3]))[-1]
+    bad = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    bad[last][0] = float("inf")
+    model.load_state_dict(bad)
+    yb = model.predict(xd, 2, to_x=True)
+    assert not torch.isfinite(yb).all()
+    with pytest.raises(LnsError, match=r"non-finite values in the output of .*decoder"):
+        model._engine(xd).check_finite(3, xd.device)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    eng = model._engine(xd)
+    eng.set_option("track_nonfinite", 1)
+    y1 = model.predict(xd, 3, to_x=True)
+    eng.check_finite(3)
+    assert torch.equal(y0, y1)
+    xi = x.copy()
+    xi[1, 0, 3, 3] = np.inf
+    model.predict(torch.from_numpy(xi).cuda(), 5, to_x=True)
+    with pytest.raises(LnsError, match=r"non-finite"):
+        eng.check_finite(3)
+    eng.set_option("track_nonfinite", 0)
+
+
+def test_op_conv_amax_runs_on_the_callers_stream():
+    """lns_op_conv2d takes the input's per-sample maximum on the CALLER's stream -- with x produced on a
+    non-blocking side stream right before the call, a maximum taken on the null stream would be too small and the
+    f16x2 scale would overflow."""
+    _need_gpu()
+    import gpu_checks as gc
+    rng = np.random.default_rng(3)
+    B, C, H, W = 4, 64, 32, 32
+    w = (rng.standard_normal((64, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    side = torch.cuda.Stream()
+    big = torch.from_numpy((rng.standard_normal((B, C, H, W)) * 3e4).astype(np.float32)).cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        x = torch.zeros_like(big)
+        for _ in range(20):                       # keep the side stream busy so that a null-stream amax would run early
+            x = x * 0.5 + big * 0.5
+        y = gc.conv2d_gpu(x, w, None, 3, pad=1, variant=gc.CV_F64)
+        side.synchronize()
+    ref = gc.conv2d_gpu(x.clone(), w, None, 3, pad=1, variant=-1)      # fp32 MFMA kernel
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert rel_l2(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
 
 
 def test_overlapped_rollout_equals_single_stream():

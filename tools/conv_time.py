@@ -31,6 +31,9 @@ cases = {
     "k1_toout_gelu_res": dict(B=64, Cin=512, Cout=64, H=64, W=64, k=1, ss=True, act=0, act_out=2, res=True),
     "lat_d4": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0, dil=4),
     "lat_b256": dict(B=256, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0),
+    "lat_d2": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0, dil=2),
+    "up32": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, up=(32, 32), ss=False, act=0),
+    "c32_64": dict(B=64, Cin=128, Cout=64, H=32, W=32, k=3, ss=True, act=1),
 }
 NREP = 5
 which = [a for a in sys.argv[1:] if not a.startswith("--") and a in cases] or list(cases)
@@ -73,7 +76,7 @@ for name in which:
     res = torch.randn(B, Cout, Hv, Wv, device="cuda") if c.get("res") else None
     def run():
         rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, Hv, Wv, gc._hp(w), gc._hp(bias), Cout, k, 1, dil, p, p, p, p, 1, 1,
-                             ss.data_ptr(), c["act"], c.get("act_out", 0), res.data_ptr() if res is not None else None, None, y.data_ptr(), c.get("v", VARIANT if k == 3 else 7), None, None)
+                             ss.data_ptr() if c.get("ss", True) else None, c["act"], c.get("act_out", 0), res.data_ptr() if res is not None else None, None, y.data_ptr(), c.get("v", VARIANT if k == 3 else 7), None, None)
         assert rc == 0
     for _ in range(NREP):
         run()

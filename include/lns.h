@@ -188,6 +188,24 @@ int lns_rollout_latent(lns_engine* e, const float* z_in, const float* param, int
  * the hot path depends on it. */
 int lns_check_finite(lns_engine* e, int B, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training rollout of the latent propagator ------------------------------------------------
+ * Reference: LatentDynamics.forward, train_stage2_ns2d.py:126-141 (SW / two-phase: same text) -- z_pred[:, t] =
+ * propagator(z_pred[:, t-1]) started at z_in -- feeding loss.backward() at train_stage2_ns2d.py:215.  The loss is the
+ * caller's (a Python callable in the reference): lns_train_forward returns z_pred [B,T,c,h,w] and keeps a tape of the
+ * step's intermediates in `workspace`; lns_train_backward takes dL/dz_pred and writes the gradient of every propagator
+ * parameter (BPTT over the T steps, accumulated in a fixed order: deterministic) and, if asked, of z_in.
+ * `params` / `grads`: arrays of lns_num_params() DEVICE pointers indexed like lns_param_info (entries of tensors that
+ * do not belong to the propagator are ignored and may be null); parameters are read from the device at every call
+ * (an optimiser updates them in place between calls) -- lns_set_weight / lns_finalize_weights are not involved.
+ * All contractions run on the exact-fp32 matrix instruction.  Unconditional propagators (NS2d, SW, two-phase);
+ * LNS_EINVAL for the conditional one.  The same workspace and parameter values must be used for the backward call. */
+int lns_train_workspace_bytes(lns_engine* e, int B, int h, int w, int T, size_t* bytes);
+int lns_train_forward(lns_engine* e, const float* const* params, const float* z_in, int B, int h, int w, int T,
+                      float* z_pred, void* workspace, size_t workspace_bytes, void* stream);
+int lns_train_backward(lns_engine* e, const float* const* params, const float* z_in, const float* z_pred,
+                       const float* grad_z_pred, int B, int h, int w, int T, float* const* grads, float* grad_z_in,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- diagnostics -------------------------------------------------------- */
 /* Layer trace: when enabled the run calls synchronise after every reference
  * module boundary and keep a host copy of its output (tests compare them with

@@ -60,6 +60,7 @@ SYMBOLS = [
     "lns_create_error", "lns_create", "lns_destroy", "lns_last_error", "lns_num_params",
     "lns_param_info", "lns_set_weight", "lns_finalize_weights", "lns_latent_shape", "lns_prepare",
     "lns_encode", "lns_encode_cond", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite", "lns_set_option",
+    "lns_train_workspace_bytes", "lns_train_forward", "lns_train_backward",
     "lns_trace_enable", "lns_trace_count", "lns_trace_info", "lns_trace_copy",
     "lns_timing_enable", "lns_timing_count", "lns_timing_info",
     "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block", "lns_metric_rel_l2", "lns_metric_rel_l2_ch",
@@ -116,6 +117,10 @@ def lib():
         L.lns_check_finite.argtypes = [vp, i, vp, c.c_size_t, vp]
     if hasattr(L, "lns_set_option"):
         L.lns_set_option.argtypes = [vp, c.c_char_p, c.c_long]
+    if hasattr(L, "lns_train_forward"):
+        L.lns_train_workspace_bytes.argtypes = [vp, i, i, i, i, c.POINTER(c.c_size_t)]
+        L.lns_train_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, c.c_size_t, vp]
+        L.lns_train_backward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, c.c_size_t, vp]
     L.lns_trace_enable.argtypes = [vp, i]
     L.lns_trace_count.argtypes = [vp]
     L.lns_trace_info.argtypes = [vp, i, c.c_char_p, i, i64p]

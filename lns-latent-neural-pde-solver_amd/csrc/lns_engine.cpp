@@ -1496,8 +1496,11 @@ int lns_create(const lns_config* cfg, lns_engine** out) {
     return LNS_OK;
 }
 
+void lns_train_release(const lns_engine* e);
+
 void lns_destroy(lns_engine* e) {
     if (!e) return;
+    lns_train_release(e);
     for (auto* m : {&e->enc_plans, &e->dec_plans, &e->prop_plans})
         for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
     if (e->d_weights) (void)hipFree(e->d_weights);
@@ -2268,3 +2271,5 @@ int lns_op_fourier_block(const float* x, int B, int Cin, int Cout, int H, int W,
 }
 
 }  // extern "C"
+
+#include "lns_train.inc"

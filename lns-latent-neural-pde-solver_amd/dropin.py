@@ -124,7 +124,7 @@ def _grow_tree(root, table, strip=""):
         if is_buffer:
             node.register_buffer(parts[-1], val)
         else:
-            node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
+            node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=True))     # as the reference's nn.Modules
 
 
 class _Hosted(_TreeWatch):
@@ -288,6 +288,40 @@ class SimpleCNNConditional(SimpleCNN):        # train_stage2_twophase_conditiona
 
 
 # ---------------------------------------------------------------------------
+class _LatentRolloutFn(torch.autograd.Function):
+    """z_pred = rollout(z0; propagator parameters) on the HIP engine, differentiable w.r.t. the parameters and z0
+    (include/lns.h "training rollout"; csrc/lns_train.inc).  The parameters are read from their device tensors at every
+    call, so an optimiser's in-place updates need no re-upload."""
+
+    @staticmethod
+    def forward(ctx, own, names, T, z0, *tensors):
+        if not z0.is_cuda:
+            raise LnsError("the LNS drop-in runs on HIP device tensors only (input is on %s); there is no CPU fallback" % z0.device)
+        eng = own._eng
+        params = {k: t.detach() for k, t in zip(names, tensors)}
+        for k, t in params.items():
+            if not t.is_cuda:
+                raise LnsError("training rollout: parameter %s is not on the HIP device (call model.cuda())" % k)
+        with torch.cuda.device(z0.device):
+            z_pred, ws = eng.train_forward(params, z0.detach(), T)
+        ctx.own, ctx.names, ctx.ws = own, names, ws
+        ctx.save_for_backward(z0, z_pred, *tensors)
+        return z_pred
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        z0, z_pred, *tensors = ctx.saved_tensors
+        params = {k: t.detach() for k, t in zip(ctx.names, tensors)}
+        with torch.cuda.device(z0.device):
+            grads, gz = ctx.own._eng.train_backward(params, z0, z_pred, grad_out.contiguous().float(), ctx.ws,
+                                                    need_z_grad=ctx.needs_input_grad[3])
+        out = [None, None, None, gz]
+        for i, k in enumerate(ctx.names):
+            out.append(grads[k] if ctx.needs_input_grad[4 + i] else None)
+        return tuple(out)
+
+
+# ---------------------------------------------------------------------------
 class LatentDynamics(_Hosted):
     """`LatentDynamics` of train_stage2_ns2d.py:90-158 (and the SW / two-phase variants)."""
     _family = "ns2d"
@@ -339,15 +373,30 @@ class LatentDynamics(_Hosted):
         return self._ae.decode(z)
 
     def forward(self, z_in, z_out, *rest):
-        """forward(z_in, z_out, loss_fn) -- conditional: forward(z_in, z_out, param, loss_fn): the loss VALUE of the
-        latent rollout started at z_in[:, 0] against the pre-encoded targets z_out [B,t_out,c,h,w]
-        (train_stage2_ns2d.py:126-141; conditional train_stage2_twophase_conditional.py:160-175), i.e. the quantity
-        a stage-2 validation pass reports.  The HIP path has no backward: calling it with autograd enabled raises
-        instead of returning a loss that silently carries no gradient."""
+        """forward(z_in, z_out, loss_fn) -- conditional: forward(z_in, z_out, param, loss_fn): the loss of the latent
+        rollout started at z_in[:, 0] against the pre-encoded targets z_out [B,t_out,c,h,w]
+        (train_stage2_ns2d.py:126-141; conditional train_stage2_twophase_conditional.py:160-175).
+        With autograd enabled (training, train_stage2_ns2d.py:213-215) the rollout runs through `_LatentRolloutFn`:
+        the HIP training forward keeps a tape and `loss.backward()` runs the HIP backward through time, filling `.grad`
+        of the propagator's parameters.  Under torch.no_grad() (validation) it is the inference rollout.
+        The conditional propagator has no HIP backward yet: with autograd enabled it raises instead of returning a
+        loss that silently carries no gradient."""
+        if torch.is_grad_enabled() and not self._conditional:
+            if len(rest) != 1:
+                raise TypeError("forward() takes (z_in, z_out, loss_fn)")
+            loss_fn, = rest
+            if z_in.dim() != 5 or z_in.shape[1] != 1:
+                raise AssertionError("z_in must be [B,1,c,h,w] (t_in == 1)")
+            z0 = z_in[:, 0].contiguous().float()
+            own = self._owner
+            prefix = "propagator."
+            names = [k for k, _ in own.named_parameters() if k.startswith(prefix)]
+            tensors = [dict(own.named_parameters())[k] for k in names]
+            z_pred = _LatentRolloutFn.apply(own, names, int(z_out.shape[1]), z0, *tensors)
+            return loss_fn(z_pred, z_out)
         if torch.is_grad_enabled():
-            raise NotImplementedError("the latent rollout runs on hand-written HIP kernels without a backward pass: "
-                                      "call forward() under torch.no_grad() for the loss value (training the "
-                                      "propagator needs autograd and is outside the accelerated inference path)")
+            raise NotImplementedError("the conditional propagator's latent rollout has no HIP backward pass yet: call "
+                                      "forward() under torch.no_grad() for the loss value")
         param = None
         if self._conditional:
             if len(rest) != 2:

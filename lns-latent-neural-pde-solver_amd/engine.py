@@ -301,6 +301,49 @@ class Engine:
                                                ws.data_ptr(), ws.numel(), self._stream(z)), "lns_rollout_latent")
         return out, z_last
 
+    # -- training rollout of the propagator (include/lns.h "training rollout") ------------------------------------
+    def _ptr_array(self, tensors):
+        """ctypes array of device pointers in parameter-table order; tensors: {key: fp32 contiguous device tensor}."""
+        arr = (ctypes.c_void_p * len(self.params))()
+        for i, (key, shape, _) in enumerate(self.params):
+            t = tensors.get(key)
+            if t is None:
+                arr[i] = None
+                continue
+            if not t.is_cuda or t.dtype is not __import__("torch").float32 or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+                raise LnsError("training rollout: %s must be a contiguous fp32 device tensor of shape %s" % (key, tuple(shape)))
+            arr[i] = t.data_ptr()
+        return arr
+
+    def train_forward(self, params, z_in, T):
+        """z_pred [B,T,c,h,w] of the latent rollout started at z_in [B,c,h,w], with the tape kept for train_backward.
+        params: {state_dict key: device tensor} of (at least) the propagator's parameters."""
+        import torch
+        z_in = self._dev(z_in)
+        B, c, h, w = z_in.shape
+        n = ctypes.c_size_t(0)
+        self._check(self._L.lns_train_workspace_bytes(self._h, B, h, w, int(T), ctypes.byref(n)), "lns_train_workspace_bytes")
+        ws = torch.empty(int(n.value), dtype=torch.uint8, device=z_in.device)
+        z_pred = torch.empty((B, int(T), c, h, w), dtype=torch.float32, device=z_in.device)
+        self._check(self._L.lns_train_forward(self._h, self._ptr_array(params), z_in.data_ptr(), B, h, w, int(T), z_pred.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), self._stream(z_in)), "lns_train_forward")
+        return z_pred, ws
+
+    def train_backward(self, params, z_in, z_pred, grad_z_pred, ws, need_z_grad=False):
+        """{key: gradient tensor} of every propagator parameter (+ grad of z_in if asked) for dL/dz_pred."""
+        import torch
+        z_in = self._dev(z_in)
+        g = self._dev(grad_z_pred)
+        B, T, c, h, w = z_pred.shape
+        prefix = self.cfg.prop_prefix.decode()
+        grads = {k: torch.empty(tuple(shp), dtype=torch.float32, device=z_in.device)
+                 for k, shp, _ in self.params if k.startswith(prefix)}
+        gz = torch.empty_like(z_in) if need_z_grad else None
+        self._check(self._L.lns_train_backward(self._h, self._ptr_array(params), z_in.data_ptr(), z_pred.data_ptr(), g.data_ptr(),
+                                               B, h, w, T, self._ptr_array(grads), gz.data_ptr() if gz is not None else None,
+                                               ws.data_ptr(), ws.numel(), self._stream(z_in)), "lns_train_backward")
+        return grads, gz
+
     def check_finite(self, B, device=None):
         """Raises LnsError naming the first layer / sample whose output held inf or NaN in the LAST call (encode /
         decode / propagate / rollout) for batch B.  Coverage: every tensor a layer of that call wrote, including

@@ -6,6 +6,9 @@ Tolerances (fp32; north star: decoded fields within 1e-4 rel-L2 of the reference
   single kernel / single stage  2e-6 .. 2e-5   (fp32 accumulation-order noise)
   rollout, T <= 64               1e-4
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -644,3 +647,114 @@ def test_packed_fp32_corun():
     for mode in ("alone", "corun"):
         assert res[mode]["scalar_mismatches"] == 0, res
     assert res["alone"]["packed_mismatches"] == 0, res        # single-stream runs never failed
+
+
+# ---- the latent TRAINING rollout, forward + backward through time on the HIP engine ---------------------
+GRAD_CASES = ["ns2d_mini", "twophase", "sw_half_periodic"]
+GRAD_TOL = 1e-4          # rel-L2 per parameter tensor against the REAL reference's loss.backward()
+
+
+def _grad_setup(case):
+    import torch.nn.functional as F
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grads_%s.npz" % case))
+    meta = json.loads(bytes(g["meta"]).decode())
+    args = config.preset(meta["preset"])
+    model, _ = gc.build_models(args, meta["weight_seed"])
+    B, T = meta["B"], meta["T"]
+    c, h, w = meta["latent"]
+    z_in = torch.from_numpy(filler.normal("z_in", (B, 1, c, h, w), meta["input_seed"]) * np.float32(meta["z_scale"])).cuda()
+    z_out = torch.from_numpy(filler.normal("z_out", (B, T, c, h, w), meta["input_seed"]) * np.float32(meta["z_scale"])).cuda()
+    return g, meta, model, z_in, z_out, F.smooth_l1_loss
+
+
+@pytest.mark.parametrize("case", GRAD_CASES)
+def test_training_rollout_gradients_match_reference(case):
+    """LatentDynamics.forward(z_in, z_out, loss_fn) with autograd enabled + loss.backward() (train_stage2_ns2d.py:126-141,
+    213-215) on the HIP engine: loss, z_pred, every propagator parameter's gradient and the gradient of z_in against the
+    REAL reference's (tools/make_golden.py grads), circular / zero / half-periodic padding, dilation 2 and 3."""
+    _need_gpu()
+    g, meta, model, z_in, z_out, loss_fn = _grad_setup(case)
+    for p_ in model._ae.parameters():
+        p_.requires_grad_(False)
+    z_in.requires_grad_(True)
+    loss = model(z_in, z_out, loss_fn)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6 * abs(float(g["loss"])) + 1e-7, (loss.item(), float(g["loss"]))
+    with torch.no_grad():
+        zp = model._engine(z_in).rollout_latent(z_in[:, 0].contiguous(), meta["T"], to_x=False)[0]
+    assert rel_l2(zp.cpu().numpy(), g["z_pred"]) < 2e-5
+    params = dict(model.named_parameters())
+    sub = meta["sub"]
+    worst = []
+    for k in meta["keys"]:
+        gr = params[k].grad
+        assert gr is not None and torch.isfinite(gr).all(), k
+        gh = gr.detach().cpu().numpy().astype(np.float64).ravel()
+        ref32, ref64 = g["gsub:" + k].astype(np.float64), g["gsub_f64:" + k].astype(np.float64)
+        own = rel_l2(ref32, ref64)                               # the reference's own fp32 deviation on this tensor
+        e32, e64 = rel_l2(gh[::sub], ref32), rel_l2(gh[::sub], ref64)
+        en = abs(np.sqrt((gh ** 2).sum()) / float(g["gnorm_f64:" + k]) - 1.0)
+        worst.append((max(e32, e64), k, e32, e64, own, en))
+        assert e64 <= max(GRAD_TOL, 3.0 * own), (k, e32, e64, own)
+        assert e32 <= max(GRAD_TOL, 3.0 * own), (k, e32, e64, own)
+        assert en <= max(GRAD_TOL, 3.0 * own), (k, en)
+    print(case, "worst tensors:", sorted(worst, reverse=True)[:3])
+    assert rel_l2(z_in.grad.cpu().numpy(), g["grad_z_in_f64"]) <= GRAD_TOL
+    assert all(p_.grad is None for p_ in model._ae.parameters())     # frozen autoencoder: untouched
+
+
+def test_training_rollout_properties():
+    """Size-independent properties of the HIP backward: bit-reproducible; linear in the batch (the gradient of the mean
+    loss over 4 trajectories is the mean of the two halves' gradients); consistent with a central finite difference of
+    the loss along a random direction in parameter space; an optimiser step changes the next loss (parameters are read
+    from their device tensors at every call)."""
+    _need_gpu()
+    g, meta, model, z_in, z_out, loss_fn = _grad_setup("ns2d_mini")
+    for p_ in model._ae.parameters():
+        p_.requires_grad_(False)
+    names = [k for k in meta["keys"]]
+    params = dict(model.named_parameters())
+    z4_in = torch.cat([z_in, z_in.flip(0) * 0.7 + 0.1], 0)
+    z4_out = torch.cat([z_out, z_out.flip(0) * 0.9 - 0.05], 0)
+
+    def grads_of(zi, zo):
+        for k in names:
+            params[k].grad = None
+        loss = model(zi, zo, loss_fn)
+        loss.backward()
+        return loss.item(), {k: params[k].grad.detach().clone() for k in names}
+    l_a, g_a = grads_of(z4_in, z4_out)
+    l_b, g_b = grads_of(z4_in, z4_out)
+    assert l_a == l_b and all(torch.equal(g_a[k], g_b[k]) for k in names)                 # deterministic
+    _, g_1 = grads_of(z4_in[:2], z4_out[:2])
+    _, g_2 = grads_of(z4_in[2:], z4_out[2:])
+    for k in names:
+        assert rel_l2((0.5 * (g_1[k] + g_2[k])).cpu().numpy(), g_a[k].cpu().numpy()) < 2e-5, k
+    # directional derivative: (L(theta + eps v) - L(theta - eps v)) / (2 eps)  vs  <grad, v>
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    v = {k: torch.randn(params[k].shape, device="cuda", generator=gen) * params[k].detach().abs().mean() for k in names}
+    dot = sum((g_a[k] * v[k]).sum().item() for k in names)
+    eps = 2e-2
+
+    with torch.no_grad():
+        for k in names:
+            params[k].add_(eps * v[k])
+    lp = model(z4_in, z4_out, loss_fn).item()
+    with torch.no_grad():
+        for k in names:
+            params[k].add_(-2 * eps * v[k])
+    lm = model(z4_in, z4_out, loss_fn).item()
+    with torch.no_grad():
+        for k in names:
+            params[k].add_(eps * v[k])
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - dot) <= 2e-2 * abs(dot) + 1e-6, (fd, dot)
+    # one SGD step on the propagator lowers this batch's loss
+    l0, g0 = grads_of(z4_in, z4_out)
+    with torch.no_grad():
+        for k in names:
+            params[k].add_(-0.05 * g0[k])
+    assert model(z4_in, z4_out, loss_fn).item() < l0

@@ -12,6 +12,7 @@ fp64 (`model.double()`), on deterministic synthetic weights
     python tools/make_golden.py            # all cases
     python tools/make_golden.py ns2d_mini  # one case
     python tools/make_golden.py ens        # reference fp32 ensembles of the long-horizon fixtures
+    python tools/make_golden.py grads      # loss.backward() of the latent training rollout
 """
 import json
 import os
@@ -217,6 +218,61 @@ def add_ensembles(which):
         print("%-20s ensemble of %d: max/min @T %.3e / %.3e" % (name, len(desc), err[:, -1].max(), err[:, -1].min()))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Gradients of the latent training rollout: the REAL reference's `LatentDynamics.forward(z_in, z_out,
+# F.smooth_l1_loss)` + `loss.backward()` (train_stage2_ns2d.py:126-141,213-215) on filler weights and filler latents,
+# fp32 and fp64.  Stored per propagator parameter: the L2 norm of its gradient and every `sub`-th element (the D = 128
+# models have 1.3 M propagator parameters), plus the loss, z_pred and the gradient w.r.t. z_in.
+# ---------------------------------------------------------------------------------------------------------------
+GRAD_CASES = {"ns2d_mini": ("ns2d_mini", 4, 3), "twophase": ("twophase", 3, 37), "sw_half_periodic": ("sw_half_periodic", 2, 37)}
+
+
+def make_grad_goldens(which=None):
+    import torch.nn.functional as F
+    for name, (preset, T, sub) in GRAD_CASES.items():
+        if which and name not in which:
+            continue
+        args = config.preset(preset)
+        B = 2
+        out = {}
+        t0 = time.time()
+        for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+            model = ref_models.build_reference_dynamics(args, WEIGHT_SEED, dtype=dt)
+            model.train()
+            ae = model.vq_ae if hasattr(model, "vq_ae") else model.ae
+            with torch.no_grad():
+                x, _ = make_inputs(args, B)
+                zs = model.x_to_z(torch.from_numpy(x).to(dt))          # only for the latent shape
+            c, h, w = zs.shape[1:]
+            z_in = torch.from_numpy(filler.normal("z_in", (B, 1, c, h, w), INPUT_SEED) * np.float32(0.5)).to(dt).requires_grad_(True)
+            z_out = torch.from_numpy(filler.normal("z_out", (B, T, c, h, w), INPUT_SEED) * np.float32(0.5)).to(dt)
+            for p_ in ae.parameters():
+                p_.requires_grad_(False)
+            loss = model(z_in, z_out, F.smooth_l1_loss)
+            loss.backward()
+            with torch.no_grad():
+                zp, z = [], z_in[:, 0]
+                for _ in range(T):
+                    z = model.propagator(z)
+                    zp.append(z)
+                zp = torch.stack(zp, 1)
+            out["loss" + tag] = np.float64(loss.item())
+            out["z_pred" + tag] = zp.numpy().astype(np.float32)
+            out["grad_z_in" + tag] = z_in.grad.numpy().astype(np.float32)
+            keys = []
+            for k, p_ in model.propagator.named_parameters():
+                g = p_.grad.detach().numpy().astype(np.float64).ravel()
+                keys.append("propagator." + k)
+                out["gnorm" + tag + ":" + "propagator." + k] = np.float64(np.sqrt((g ** 2).sum()))
+                out["gsub" + tag + ":" + "propagator." + k] = g[::sub].astype(np.float32)
+        meta = dict(case=name, preset=preset, B=B, T=T, sub=sub, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED, keys=keys,
+                    latent=[int(c), int(h), int(w)], loss="smooth_l1_loss (mean, beta=1)", z_scale=0.5)
+        out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        path = os.path.join(OUT, "grads_" + name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-24s T=%d %d tensors  loss %.6f  %.1f KB (%.1fs)" % ("grads_" + name, T, len(keys), out["loss"], os.path.getsize(path) / 1024, time.time() - t0))
+
+
 def make_op_goldens():
     """Standalone Fourier blocks (not reached by any model config): outputs of the
     reference's FourierBasicBlock / CondFourierBasicBlock on filler weights."""
@@ -317,6 +373,9 @@ if __name__ == "__main__":
     # `ens [case ...]`: only (re)compute the reference ensembles of the long-horizon fixtures (adds arrays to them)
     if sys.argv[1:2] == ["ens"]:
         add_ensembles(sys.argv[2:] or ENSEMBLE_CASES)
+        sys.exit(0)
+    if sys.argv[1:2] == ["grads"]:
+        make_grad_goldens(sys.argv[2:])
         sys.exit(0)
     which = sys.argv[1:] or list(CASES) + ["ops", "cond_ae"]
     if "cond_ae" in which:

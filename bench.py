@@ -197,7 +197,12 @@ def plumbing_pass(a, rank, world, dist, dev):
             z = z + 1.0
             buf[:, t] = z.mean(dim=(1, 2, 3))[:, None, None, None].expand(-1, C, H, W)
         return z
-    chunked = parallel.ChunkedGatherRollout(encode, rollout_latent, (C, H, W), B, T, a.gather_chunk, dev, gather=world > 1)
+    if a.gather_mode == "end":
+        def rollout(x, out):
+            rollout_latent(encode(x), T, out)
+        chunked = parallel.EndGatherRollout(rollout, (C, H, W), B, T, dev, gather=world > 1)
+    else:
+        chunked = parallel.ChunkedGatherRollout(encode, rollout_latent, (C, H, W), B, T, a.gather_chunk, dev, gather=world > 1)
     x = torch.full((B, C, H, W), float(rank), device=dev)
     chunked.run(x)
     full = chunked.assemble()
@@ -216,6 +221,9 @@ def main():
     ap.add_argument("--preset", default="ns2d_128")
     ap.add_argument("--gather-chunk", type=int, default=8, help="step-block size of the overlapped all-gather")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-mode", choices=["end", "chunked"], default="end",
+                    help="end: ONE all_gather_into_tensor of the decoded shards after the rollout (the north star's form); "
+                         "chunked: finished step blocks gathered on a side stream while the rest is computed")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (rehearsal)")
     ap.add_argument("--device", type=int, default=None, help="override the device index (default LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -299,7 +307,11 @@ def main():
         def _rollout_latent(z, steps, buf):
             return eng.rollout_latent(z, steps, param=param, to_x=True, out=buf)[1]
         chunked = None
-        if gather:
+        if gather and a.gather_mode == "end":
+            def _rollout_all(xx, oo):
+                eng.rollout(xx, T, param=param, to_x=True, out=oo)
+            chunked = parallel.EndGatherRollout(_rollout_all, (args.in_channels, args.Ly, args.Lx), B, T, dev, gather=True)
+        elif gather:
             chunked = parallel.ChunkedGatherRollout(eng.encode, _rollout_latent, (args.in_channels, args.Ly, args.Lx),
                                                     B, T, a.gather_chunk, dev, gather=True)
 
@@ -307,7 +319,7 @@ def main():
             if chunked is None:
                 eng.rollout(x, T, param=param, to_x=True, out=out)
             else:
-                chunked.run(x)       # chunked rollout; each finished step block is all-gathered on a side stream
+                chunked.run(x)       # end: rollout, then one all-gather; chunked: step blocks gathered on a side stream
 
     for _ in range(a.warmup):
         one_pass()
@@ -317,6 +329,8 @@ def main():
         one_pass()
     barrier()
     dt = time.perf_counter() - t0
+    if chunked is not None and hasattr(chunked, "finish_timing"):
+        chunked.finish_timing()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -339,10 +353,24 @@ def main():
         "config": {"workload": "%s, %d-step latent rollout, batch=%d per GPU%s" % (
                        wl, T, B, " (BASELINE.json configs[1])" if (a.preset, B, T) == ("ns2d_128", 64, 64) else ""),
                    "preset": a.preset, "batch_per_gpu": B, "rollout_steps": T, "global_batch": B * n_gpus,
-                   "parallelism": "trajectory-sharded x%d%s" % (n_gpus, ", overlapped all-gather" if gather else ""),
+                   "parallelism": "trajectory-sharded x%d%s" % (n_gpus, (", one end-of-rollout all-gather" if a.gather_mode == "end"
+                                                                          else ", overlapped step-block all-gather") if gather else ""),
                    "streams": "single stream" if a.serial else "propagator + 3 decode streams per GPU"},
         "batch_steps_per_s": value / B,
     }
+    if world > 1:
+        # self-describing multi-GPU record: what the backend saw, what moved, what of it was exposed
+        shard_bytes = 4 * B * T * (2 * 8 * 8 if a.plumbing_only else args.in_channels * args.Ly * args.Lx)
+        exp = getattr(chunked, "exposed_ms", None) if chunked is not None else None
+        result["multi_gpu"] = {
+            "backend": dist.get_backend(), "world_size_seen_by_backend": dist.get_world_size(), "rank0_device": str(dev),
+            "gather": ("none" if not gather else a.gather_mode), "collective": "all_gather_into_tensor" if gather else None,
+            "bytes_contributed_per_rank": shard_bytes if gather else 0,
+            "bytes_received_per_rank": shard_bytes * (world - 1) if gather else 0,
+            "gathers_per_rollout": (1 if a.gather_mode == "end" else len(chunked.lens)) if gather and chunked is not None else 0,
+            "exposed_gather_ms_rank0": (sum(exp[-a.steps:]) / max(1, len(exp[-a.steps:]))) if exp else None,
+            "note": "end: the single gather is fully exposed (measured between the rollout's last kernel and the gather's "
+                    "completion on rank 0); chunked: only the last block's gather is exposed (not separately timed)"}
     if a.plumbing_only:
         result["data"] = "plumbing-only: orchestration without compute (value is NOT a measurement)"
         result["plumbing_ok"] = bool(ok)

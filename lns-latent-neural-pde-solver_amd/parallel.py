@@ -81,6 +81,52 @@ class ChunkedGatherRollout:
         return torch.cat(self.gathered, dim=1)
 
 
+class EndGatherRollout:
+    """The north star's literal form: every rank runs its whole shard's rollout, then ONE all-gather of the decoded
+    shards [B,T,C,H,W] into a preallocated [world*B,T,C,H,W] buffer (rank order along dim 0).  No collective and no
+    host synchronisation inside the rollout; the gather is fully exposed (it is what `exposed_gather_ms` measures).
+
+    rollout(x, out) writes out [B,T,C,H,W] in place."""
+
+    def __init__(self, rollout, frame_shape, B, T, device, group=None, gather=True):
+        self.rollout, self.group = rollout, group
+        self.world = dist.get_world_size(group) if (gather and dist.is_initialized()) else 1
+        self.out = torch.empty((B, T) + tuple(frame_shape), dtype=torch.float32, device=device)
+        self.full = None
+        if self.world > 1:
+            self.full = torch.empty((self.world * B, T) + tuple(frame_shape), dtype=torch.float32, device=device)
+        self.on_gpu = torch.device(device).type == "cuda"
+        self.bufs = [self.out]
+        self.exposed_ms = []            # per run: time between the end of the rollout and the end of the gather
+
+    def run(self, x):
+        import time
+        self.rollout(x, self.out)
+        if self.full is None:
+            return self.bufs
+        if self.on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_gather_into_tensor(self.full, self.out, group=self.group)
+            e1.record()
+            self._pending = (e0, e1)
+        else:
+            t0 = time.perf_counter()
+            dist.all_gather_into_tensor(self.full, self.out, group=self.group)
+            self.exposed_ms.append((time.perf_counter() - t0) * 1e3)
+        return self.bufs
+
+    def finish_timing(self):
+        """(GPU) resolve the events of the last run; call after a synchronise."""
+        p = getattr(self, "_pending", None)
+        if p is not None:
+            self.exposed_ms.append(p[0].elapsed_time(p[1]))
+            self._pending = None
+
+    def assemble(self):
+        return self.out if self.full is None else self.full
+
+
 def gather_metrics(frame, seq, group=None):
     """Validation over sharded trajectories without moving the fields: each rank reduces its own decoded rollout to
     the frame-wise [b,T,C] and sequence-wise [b,C] errors (lns_amd.metrics.relative_l2, one pass over its shard) and

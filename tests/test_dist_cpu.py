@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, T, chunk, q):
+def _worker(rank, world, port, T, chunk, q, mode="chunked"):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -49,8 +49,13 @@ def _worker(rank, world, port, T, chunk, q):
             out[:, t] = torch.from_numpy(orc.z_to_x(zz))
         return torch.from_numpy(zz)
 
-    r = parallel.ChunkedGatherRollout(encode, rollout_latent, (args.in_channels, args.Ly, args.Lx), hi - lo, T,
-                                      chunk, "cpu")
+    if mode == "end":       # the north star's form: whole rollout, then ONE all-gather into [world*B, T, C, H, W]
+        def rollout(x, out):
+            rollout_latent(encode(x), T, out)
+        r = parallel.EndGatherRollout(rollout, (args.in_channels, args.Ly, args.Lx), hi - lo, T, "cpu")
+    else:
+        r = parallel.ChunkedGatherRollout(encode, rollout_latent, (args.in_channels, args.Ly, args.Lx), hi - lo, T,
+                                          chunk, "cpu")
     r.run(torch.from_numpy(x_all[lo:hi]))
     full = r.assemble().numpy()
     if rank == 0:
@@ -73,6 +78,22 @@ def test_sharded_rollout_with_overlapped_gather_matches_unsharded():
         assert p.exitcode == 0
     assert shape == (4, 9, 2, 32, 32)
     assert err == 0.0          # trajectories are independent: sharded == unsharded bit for bit
+
+
+def test_sharded_rollout_with_single_end_gather_matches_unsharded():
+    """--gather-mode end: one all_gather_into_tensor of the decoded shards after the rollout (gloo, world_size 2)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, 2, q, "end")) for r in range(2)]
+    for p in procs:
+        p.start()
+    shape, err = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert shape == (4, 5, 2, 32, 32)
+    assert err == 0.0
 
 
 def _metric_worker(rank, world, port, q):
@@ -142,7 +163,18 @@ def test_bench_launches_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["plumbing_ok"] is True
     assert rec["config"]["global_batch"] == 6 and rec["steps"] == 2 and rec["warmup"] == 1
-    assert "overlapped all-gather" in rec["config"]["parallelism"]
+    assert "one end-of-rollout all-gather" in rec["config"]["parallelism"]          # the default mode
+    mg = rec["multi_gpu"]                                    # self-describing: what the backend saw, what moved
+    assert mg["backend"] == "gloo" and mg["world_size_seen_by_backend"] == 2 and mg["gather"] == "end"
+    assert mg["gathers_per_rollout"] == 1 and mg["bytes_contributed_per_rank"] == 4 * 3 * 9 * 2 * 8 * 8
+    assert mg["bytes_received_per_rank"] == mg["bytes_contributed_per_rank"] and mg["exposed_gather_ms_rank0"] >= 0.0
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--plumbing-only", "--steps", "1", "--warmup", "0", "--batch", "3", "--rollout", "9",
+                        "--gather-chunk", "2", "--gather-mode", "chunked"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert "overlapped step-block all-gather" in rec["config"]["parallelism"] and rec["plumbing_ok"] is True
+    assert rec["multi_gpu"]["gather"] == "chunked" and rec["multi_gpu"]["gathers_per_rollout"] == 4
 
 
 def test_bench_workload_labels_follow_the_preset():

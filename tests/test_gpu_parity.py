@@ -465,6 +465,43 @@ def test_full_size_rollout_properties():
     assert rel_l2(sub.cpu().numpy(), ref) < STAGE_TOL * 2
 
 
+@pytest.mark.parametrize("preset,B,T", [("sw_96x192x5", 64, 2), ("twophase_cond", 32, 3)])
+def test_full_size_properties_configs_3_and_4(preset, B, T):
+    """BASELINE configs 3 (SW 96x192x5, B=64: 48x96 sandwich planes, one block per CU) and 4 (conditional two-phase,
+    B=32: ragged 61x121 tiles, the conditional embedding pool) at their FULL batch, a few steps: finite; a sub-batch is
+    bit-identical to the same trajectories inside the full batch (what makes trajectory sharding exact); the sub-batch
+    is within 4e-5 of the oracle; the multi-stream rollout equals the single-stream one bit for bit under several
+    schedules (reference shapes: modules/autoencoder2d_nonsquared.py:148-247)."""
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    args = config.preset(preset)
+    model, orc = gc.build_models(args, 1)
+    x = filler.normal("xfull_" + preset, (B, args.in_channels, args.Ly, args.Lx), 5)
+    param = filler.uniform01("pfull", B, 5).astype(np.float32) if args.family == "twophase_cond" else None
+    xd = torch.from_numpy(x).cuda()
+    pd = torch.from_numpy(param).cuda() if param is not None else None
+    extra = (pd,) if pd is not None else ()
+    eng = model._engine(xd)
+    eng.set_option("decode_group", 1)
+    eng.timing_enable(True)            # diagnostics mode = everything on the caller's stream
+    ref = model.predict(xd, T, *extra, to_x=True).clone()
+    eng.timing_enable(False)
+    assert torch.isfinite(ref).all()
+    for opts in (dict(decode_group=1), dict(decode_group=2, decode_streams=2), dict(decode_group=0), dict(decode_group=1, decode_streams=3, overlap=1)):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        y = model.predict(xd, T, *extra, to_x=True)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref), (preset, opts)
+    lo = B // 3
+    sub_extra = (pd[lo:lo + 2].contiguous(),) if pd is not None else ()
+    sub = model.predict(xd[lo:lo + 2].contiguous(), T, *sub_extra, to_x=True)
+    assert torch.equal(ref[lo:lo + 2], sub), preset
+    o = orc.predict(x[lo:lo + 2], T, param=param[lo:lo + 2] if param is not None else None, to_x=True)
+    assert rel_l2(sub.cpu().numpy(), o) < 4e-5, preset
+
+
 # ---------------------------------------------------------------------------------------------------
 # "next rows" (SURVEY 8f): fused denormalise + relative-L2 metric, bulk dataset encode
 # ---------------------------------------------------------------------------------------------------
@@ -519,7 +556,9 @@ def test_metric_matches_reference_golden(name):
 @pytest.mark.parametrize("preset", ["ns2d_mini", "twophase_cond"])
 def test_teacher_forced_loss_matches_oracle(preset):
     """LatentDynamics.forward(z_in, z_out[, param], loss_fn): loss value of the latent rollout against pre-encoded
-    targets (train_stage2_ns2d.py:126-141), vs the oracle; with autograd enabled it must raise (no backward)."""
+    targets (train_stage2_ns2d.py:126-141), vs the oracle.  With autograd enabled the unconditional model runs the HIP
+    training rollout (same loss, differentiable: test_training_rollout_*); the conditional one, which has no HIP
+    backward yet, must raise rather than return a loss that silently carries no gradient."""
     _need_gpu()
     import gpu_checks as gc
     import lns_oracle
@@ -538,8 +577,12 @@ def test_teacher_forced_loss_matches_oracle(preset):
     with torch.no_grad():
         loss = model(zi, zo, *extra, F.smooth_l1_loss)
     assert abs(float(loss) - ref) <= 2e-5 * abs(ref), (float(loss), ref)
-    with pytest.raises(NotImplementedError):
-        model(zi, zo, *extra, F.smooth_l1_loss)
+    if param is not None:
+        with pytest.raises(NotImplementedError):
+            model(zi, zo, *extra, F.smooth_l1_loss)
+    else:
+        lt = model(zi, zo, F.smooth_l1_loss)
+        assert lt.requires_grad and abs(float(lt) - ref) <= 2e-5 * abs(ref), (float(lt), ref)
 
 
 @pytest.mark.gpu

@@ -197,11 +197,12 @@ int lns_check_finite(lns_engine* e, int B, void* workspace, size_t workspace_byt
  * `params` / `grads`: arrays of lns_num_params() DEVICE pointers indexed like lns_param_info (entries of tensors that
  * do not belong to the propagator are ignored and may be null); parameters are read from the device at every call
  * (an optimiser updates them in place between calls) -- lns_set_weight / lns_finalize_weights are not involved.
- * All contractions run on the exact-fp32 matrix instruction.  Unconditional propagators (NS2d, SW, two-phase);
- * LNS_EINVAL for the conditional one.  The same workspace and parameter values must be used for the backward call. */
+ * All contractions run on the exact-fp32 matrix instruction.  Plain propagators (NS2d, SW, two-phase) and the
+ * conditional one (train_stage2_twophase_conditional.py:25-121; `param` [B], no gradient w.r.t. it).  The same
+ * workspace and parameter values must be used for the backward call. */
 int lns_train_workspace_bytes(lns_engine* e, int B, int h, int w, int T, size_t* bytes);
-int lns_train_forward(lns_engine* e, const float* const* params, const float* z_in, int B, int h, int w, int T,
-                      float* z_pred, void* workspace, size_t workspace_bytes, void* stream);
+int lns_train_forward(lns_engine* e, const float* const* params, const float* z_in, const float* param_or_null,
+                      int B, int h, int w, int T, float* z_pred, void* workspace, size_t workspace_bytes, void* stream);
 int lns_train_backward(lns_engine* e, const float* const* params, const float* z_in, const float* z_pred,
                        const float* grad_z_pred, int B, int h, int w, int T, float* const* grads, float* grad_z_in,
                        void* workspace, size_t workspace_bytes, void* stream);

@@ -18,6 +18,8 @@ LNS_ABI_VERSION = 2
 LNS_AE_NONE, LNS_AE_SQUARE, LNS_AE_NONSQUARED, LNS_AE_HALF_PERIODIC = 0, 1, 2, 3
 LNS_PROP_NONE, LNS_PROP_PLAIN, LNS_PROP_CONDITIONAL = 0, 1, 2
 LNS_PAD_ZEROS, LNS_PAD_CIRCULAR = 0, 1
+# status codes (include/lns.h)
+LNS_OK, LNS_EINVAL, LNS_ENOKEY, LNS_ESTATE, LNS_ENOMEM, LNS_EHIP, LNS_ENONFINITE = 0, -1, -2, -3, -4, -5, -6
 
 
 class LnsLibraryError(RuntimeError):
@@ -119,7 +121,7 @@ def lib():
         L.lns_set_option.argtypes = [vp, c.c_char_p, c.c_long]
     if hasattr(L, "lns_train_forward"):
         L.lns_train_workspace_bytes.argtypes = [vp, i, i, i, i, c.POINTER(c.c_size_t)]
-        L.lns_train_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, c.c_size_t, vp]
+        L.lns_train_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, vp, c.c_size_t, vp]
         L.lns_train_backward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, c.c_size_t, vp]
     L.lns_trace_enable.argtypes = [vp, i]
     L.lns_trace_count.argtypes = [vp]

@@ -1159,19 +1159,20 @@ struct Runner {
             B.bs[SP_EXT0 + i] = ext[i].bs; B.bs2[SP_EXT0 + i] = ext[i].bs2; B.bdiv[SP_EXT0 + i] = ext[i].bdiv;
         }
         // the amax side channel accumulates with atomic max: every run of the plan starts from zero
+        // has this (plan, arena) pair already run in this call?  (the first run finds whatever the workspace held before)
+        bool seen = false;
+        if (e->ran_ws) {
+            const size_t off = (size_t)(arena_base - static_cast<const char*>(e->ran_ws));
+            for (const auto& r : e->ran) seen = seen || (r.kind == plan.kind && r.key == plan.key && r.arena_off == off);
+            if (!seen) e->ran.push_back({plan.kind, plan.key, off});
+        }
         if (plan.amax_bytes) {
-            // "track_nonfinite": what this region recorded in its PREVIOUS run (an earlier step of a rollout, another
-            // decode group) is folded into the engine's sticky word before it is zeroed
-            if (e->opt_track_nonfinite && e->d_sticky)
+            // "track_nonfinite": what this region recorded in its PREVIOUS run of this call (an earlier step of the
+            // rollout, another decode group) is folded into the engine's sticky word before it is zeroed
+            if (e->opt_track_nonfinite && e->d_sticky && seen)
                 HIPCHK(e, launch_amax_sticky(reinterpret_cast<const unsigned*>(arena_base + plan.amax_off), (int)(plan.amax_bytes / 4),
                                              e->d_sticky + plan.kind, stream));
             HIPCHK(e, hipMemsetAsync(arena_base + plan.amax_off, 0, plan.amax_bytes, stream));
-        }
-        if (e->ran_ws) {
-            const size_t off = (size_t)(arena_base - static_cast<const char*>(e->ran_ws));
-            bool seen = false;
-            for (const auto& r : e->ran) seen = seen || (r.kind == plan.kind && r.key == plan.key && r.arena_off == off);
-            if (!seen) e->ran.push_back({plan.kind, plan.key, off});
         }
         for (const Op& op : plan.ops) {
             if (skip_step_invariant && (op.type == OP_CONDBASE || op.type == OP_CONDBLK)) continue;

@@ -37,4 +37,15 @@ struct WgradArgs {
 };
 hipError_t launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 
+// conditional propagator: per-channel reductions / modulation of fields, per-sample vector network (one block each)
+hipError_t launch_chan_dot(const float* a, const float* b2, float* out, int BC, int HW, int accumulate, hipStream_t s);
+hipError_t launch_chan_scale(const float* x, const float* m, const float* add, float* y, int BC, int HW, hipStream_t s);
+hipError_t launch_vec_fourier(const float* param, float* out, int B, int E, hipStream_t s);
+hipError_t launch_vec_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I, int O, hipStream_t s);
+hipError_t launch_vec_linear_bwd(const float* dy, const float* x, const float* W, float* dx, int dx_acc, float* dW, float* db, int p_acc,
+                                 int B, int I, int O, hipStream_t s);
+hipError_t launch_vec_gelu(const float* u, const float* dy, float* out, int n, hipStream_t s);
+hipError_t launch_vec_gn(const float* x, const float* gamma, const float* beta, float* y, float* stats, const float* dy, float* dx,
+                         float* dgamma, float* dbeta, int p_acc, int B, int D, float eps, hipStream_t s);
+
 }  // namespace lns

@@ -284,4 +284,152 @@ hipError_t launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Conditional propagator (train_stage2_twophase_conditional.py:25-121): per-channel reductions / modulation of the
+// fields, and the small per-sample vector network (fourier embedding -> MLP -> per-block Linear / GroupNorm / 1x1 convs on
+// [B, D, 1, 1]).  The vector kernels are one 256-thread block each: B <= 1024 samples x <= 512 features.
+// ---------------------------------------------------------------------------------------------------------------------
+// out[b][c] (+)= sum_p a[b][c][p] * (b2 ? b2[b][c][p] : 1): one wave per (b, c), fixed order
+__global__ __launch_bounds__(256) void chan_dot_kernel(const float* a, const float* b2, float* out, int BC, int HW, int accumulate) {
+    const int bc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (bc >= BC) return;
+    const float* pa = a + (long)bc * HW;
+    const float* pb = b2 ? b2 + (long)bc * HW : nullptr;
+    float s = 0.0f;
+    for (int p = lane; p < HW; p += 64) s += pb ? pa[p] * pb[p] : pa[p];
+    s = t_wave_sum(s);
+    if (lane == 0) out[bc] = accumulate ? out[bc] + s : s;
+}
+hipError_t launch_chan_dot(const float* a, const float* b2, float* out, int BC, int HW, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(chan_dot_kernel, dim3((BC + 3) / 4), dim3(256), 0, s, a, b2, out, BC, HW, accumulate);
+    return hipGetLastError();
+}
+// y[b][c][p] = (add ? add[..] : 0) + x[b][c][p] * (1 + m[b][c])
+__global__ __launch_bounds__(256) void chan_scale_kernel(const float* x, const float* m, const float* add, float* y, int BC, int HW) {
+    const long n = (long)BC * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i] * (1.0f + m[i / HW]);
+        y[i] = add ? add[i] + v : v;
+    }
+}
+hipError_t launch_chan_scale(const float* x, const float* m, const float* add, float* y, int BC, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(chan_scale_kernel, dim3(ew_blocks((long)BC * HW)), dim3(256), 0, s, x, m, add, y, BC, HW);
+    return hipGetLastError();
+}
+
+// fourier_embedding(param, E) (modules/cond_utils.py:19-38): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half)
+__global__ __launch_bounds__(256) void vec_fourier_kernel(const float* param, float* out, int B, int E) {
+    const int half = E / 2;
+    for (int i = threadIdx.x; i < B * E; i += 256) {
+        const int b = i / E, j = i - b * E;
+        float v = 0.0f;
+        if (j < 2 * half) {
+            const int k = j < half ? j : j - half;
+            const float f = expf(-9.210340371976184f * (float)k / (float)half);
+            const float arg = param[b] * f;
+            v = j < half ? cosf(arg) : sinf(arg);
+        }
+        out[i] = v;
+    }
+}
+// y[b][o] = sum_i x[b][i] W[o][i] + bias[o]   (nn.Linear / a 1x1 conv on [B, I, 1, 1]; W row-major [O][I])
+__global__ __launch_bounds__(256) void vec_linear_fwd_kernel(const float* x, const float* W, const float* bias, float* y, int B, int I, int O) {
+    for (int e = threadIdx.x; e < B * O; e += 256) {
+        const int b = e / O, o = e - b * O;
+        float s = bias ? bias[o] : 0.0f;
+        for (int i = 0; i < I; ++i) s = fmaf(x[b * I + i], W[o * I + i], s);
+        y[e] = s;
+    }
+}
+// dx[b][i] (+)= sum_o dy[b][o] W[o][i] ; dW[o][i] (+)= sum_b dy[b][o] x[b][i] ; db[o] (+)= sum_b dy[b][o]
+__global__ __launch_bounds__(256) void vec_linear_bwd_kernel(const float* dy, const float* x, const float* W, float* dx, int dx_acc,
+                                                             float* dW, float* db, int p_acc, int B, int I, int O) {
+    if (dx)
+        for (int e = threadIdx.x; e < B * I; e += 256) {
+            const int b = e / I, i = e - b * I;
+            float s = 0.0f;
+            for (int o = 0; o < O; ++o) s = fmaf(dy[b * O + o], W[o * I + i], s);
+            dx[e] = dx_acc ? dx[e] + s : s;
+        }
+    for (int e = threadIdx.x; e < O * I; e += 256) {
+        const int o = e / I, i = e - o * I;
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) s = fmaf(dy[b * O + o], x[b * I + i], s);
+        dW[e] = p_acc ? dW[e] + s : s;
+    }
+    if (db)
+        for (int o = threadIdx.x; o < O; o += 256) {
+            float s = 0.0f;
+            for (int b = 0; b < B; ++b) s += dy[b * O + o];
+            db[o] = p_acc ? db[o] + s : s;
+        }
+}
+__global__ __launch_bounds__(256) void vec_gelu_kernel(const float* u, const float* dy, float* out, int n) {   // dy null: forward
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = u[i];
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        out[i] = dy ? dy[i] * (cdf + v * 0.39894228040143267794f * expf(-0.5f * v * v)) : v * cdf;
+    }
+}
+// GroupNorm(1, D) of a [B, D, 1, 1] tensor = normalisation over the D features of a sample.  fwd: y, stats [B][2];
+// bwd: dx, dgamma (+)=, dbeta (+)=
+__global__ __launch_bounds__(256) void vec_gn_kernel(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                                     const float* dy, float* dx, float* dgamma, float* dbeta, int p_acc, int B, int D, float eps) {
+    __shared__ float sm[1024 * 2];
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* xb = x + (long)b * D;
+        float s = 0.0f;
+        for (int i = 0; i < D; ++i) s += xb[i];
+        const float mean = s / (float)D;
+        float q = 0.0f;
+        for (int i = 0; i < D; ++i) { const float d = xb[i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+        sm[2 * b] = mean; sm[2 * b + 1] = rstd;
+        if (stats) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
+        if (!dy) {
+            for (int i = 0; i < D; ++i) y[(long)b * D + i] = (xb[i] - mean) * rstd * gamma[i] + beta[i];
+        } else {
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int i = 0; i < D; ++i) { const float xh = (xb[i] - mean) * rstd, gd = dy[(long)b * D + i] * gamma[i]; s1 += gd; s2 += gd * xh; }
+            s1 /= (float)D; s2 /= (float)D;
+            for (int i = 0; i < D; ++i) {
+                const float xh = (xb[i] - mean) * rstd, gd = dy[(long)b * D + i] * gamma[i];
+                dx[(long)b * D + i] = rstd * (gd - s1 - xh * s2);
+            }
+        }
+    }
+    if (dy) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += 256) {
+            float sg = 0.0f, sb = 0.0f;
+            for (int b = 0; b < B; ++b) { const float d = dy[(long)b * D + i]; sg += d * (x[(long)b * D + i] - sm[2 * b]) * sm[2 * b + 1]; sb += d; }
+            dgamma[i] = p_acc ? dgamma[i] + sg : sg;
+            dbeta[i] = p_acc ? dbeta[i] + sb : sb;
+        }
+    }
+}
+hipError_t launch_vec_fourier(const float* param, float* out, int B, int E, hipStream_t s) {
+    hipLaunchKernelGGL(vec_fourier_kernel, dim3(1), dim3(256), 0, s, param, out, B, E);
+    return hipGetLastError();
+}
+hipError_t launch_vec_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I, int O, hipStream_t s) {
+    hipLaunchKernelGGL(vec_linear_fwd_kernel, dim3(1), dim3(256), 0, s, x, W, bias, y, B, I, O);
+    return hipGetLastError();
+}
+hipError_t launch_vec_linear_bwd(const float* dy, const float* x, const float* W, float* dx, int dx_acc, float* dW, float* db, int p_acc,
+                                 int B, int I, int O, hipStream_t s) {
+    hipLaunchKernelGGL(vec_linear_bwd_kernel, dim3(1), dim3(256), 0, s, dy, x, W, dx, dx_acc, dW, db, p_acc, B, I, O);
+    return hipGetLastError();
+}
+hipError_t launch_vec_gelu(const float* u, const float* dy, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(vec_gelu_kernel, dim3(1), dim3(256), 0, s, u, dy, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_vec_gn(const float* x, const float* gamma, const float* beta, float* y, float* stats, const float* dy, float* dx,
+                         float* dgamma, float* dbeta, int p_acc, int B, int D, float eps, hipStream_t s) {
+    if (B > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vec_gn_kernel, dim3(1), dim3(256), 0, s, x, gamma, beta, y, stats, dy, dx, dgamma, dbeta, p_acc, B, D, eps);
+    return hipGetLastError();
+}
+
 }  // namespace lns

@@ -294,7 +294,7 @@ class _LatentRolloutFn(torch.autograd.Function):
     call, so an optimiser's in-place updates need no re-upload."""
 
     @staticmethod
-    def forward(ctx, own, names, T, z0, *tensors):
+    def forward(ctx, own, names, T, z0, param, *tensors):
         if not z0.is_cuda:
             raise LnsError("the LNS drop-in runs on HIP device tensors only (input is on %s); there is no CPU fallback" % z0.device)
         eng = own._eng
@@ -303,7 +303,7 @@ class _LatentRolloutFn(torch.autograd.Function):
             if not t.is_cuda:
                 raise LnsError("training rollout: parameter %s is not on the HIP device (call model.cuda())" % k)
         with torch.cuda.device(z0.device):
-            z_pred, ws = eng.train_forward(params, z0.detach(), T)
+            z_pred, ws = eng.train_forward(params, z0.detach(), T, param=param)
         ctx.own, ctx.names, ctx.ws = own, names, ws
         ctx.save_for_backward(z0, z_pred, *tensors)
         return z_pred
@@ -315,9 +315,9 @@ class _LatentRolloutFn(torch.autograd.Function):
         with torch.cuda.device(z0.device):
             grads, gz = ctx.own._eng.train_backward(params, z0, z_pred, grad_out.contiguous().float(), ctx.ws,
                                                     need_z_grad=ctx.needs_input_grad[3])
-        out = [None, None, None, gz]
+        out = [None, None, None, gz, None]
         for i, k in enumerate(ctx.names):
-            out.append(grads[k] if ctx.needs_input_grad[4 + i] else None)
+            out.append(grads[k] if ctx.needs_input_grad[5 + i] else None)
         return tuple(out)
 
 
@@ -378,25 +378,20 @@ class LatentDynamics(_Hosted):
         (train_stage2_ns2d.py:126-141; conditional train_stage2_twophase_conditional.py:160-175).
         With autograd enabled (training, train_stage2_ns2d.py:213-215) the rollout runs through `_LatentRolloutFn`:
         the HIP training forward keeps a tape and `loss.backward()` runs the HIP backward through time, filling `.grad`
-        of the propagator's parameters.  Under torch.no_grad() (validation) it is the inference rollout.
-        The conditional propagator has no HIP backward yet: with autograd enabled it raises instead of returning a
-        loss that silently carries no gradient."""
-        if torch.is_grad_enabled() and not self._conditional:
-            if len(rest) != 1:
-                raise TypeError("forward() takes (z_in, z_out, loss_fn)")
-            loss_fn, = rest
+        of the propagator's parameters (no gradient w.r.t. `param`).  Under torch.no_grad() (validation) it is the
+        inference rollout."""
+        if torch.is_grad_enabled():
+            if len(rest) != (2 if self._conditional else 1):
+                raise TypeError("forward() takes (z_in, z_out, param, loss_fn)" if self._conditional else "forward() takes (z_in, z_out, loss_fn)")
+            cparam, loss_fn = (rest[0], rest[1]) if self._conditional else (None, rest[0])
             if z_in.dim() != 5 or z_in.shape[1] != 1:
                 raise AssertionError("z_in must be [B,1,c,h,w] (t_in == 1)")
             z0 = z_in[:, 0].contiguous().float()
             own = self._owner
-            prefix = "propagator."
-            names = [k for k, _ in own.named_parameters() if k.startswith(prefix)]
-            tensors = [dict(own.named_parameters())[k] for k in names]
-            z_pred = _LatentRolloutFn.apply(own, names, int(z_out.shape[1]), z0, *tensors)
+            named = dict(own.named_parameters())
+            names = [k for k in named if k.startswith("propagator.")]
+            z_pred = _LatentRolloutFn.apply(own, names, int(z_out.shape[1]), z0, cparam, *[named[k] for k in names])
             return loss_fn(z_pred, z_out)
-        if torch.is_grad_enabled():
-            raise NotImplementedError("the conditional propagator's latent rollout has no HIP backward pass yet: call "
-                                      "forward() under torch.no_grad() for the loss value")
         param = None
         if self._conditional:
             if len(rest) != 2:

@@ -315,17 +315,19 @@ class Engine:
             arr[i] = t.data_ptr()
         return arr
 
-    def train_forward(self, params, z_in, T):
+    def train_forward(self, params, z_in, T, param=None):
         """z_pred [B,T,c,h,w] of the latent rollout started at z_in [B,c,h,w], with the tape kept for train_backward.
-        params: {state_dict key: device tensor} of (at least) the propagator's parameters."""
+        params: {state_dict key: device tensor} of (at least) the propagator's parameters; param: [B] (conditional)."""
         import torch
         z_in = self._dev(z_in)
+        pc = self._param(param, z_in)
         B, c, h, w = z_in.shape
         n = ctypes.c_size_t(0)
         self._check(self._L.lns_train_workspace_bytes(self._h, B, h, w, int(T), ctypes.byref(n)), "lns_train_workspace_bytes")
         ws = torch.empty(int(n.value), dtype=torch.uint8, device=z_in.device)
         z_pred = torch.empty((B, int(T), c, h, w), dtype=torch.float32, device=z_in.device)
-        self._check(self._L.lns_train_forward(self._h, self._ptr_array(params), z_in.data_ptr(), B, h, w, int(T), z_pred.data_ptr(),
+        self._check(self._L.lns_train_forward(self._h, self._ptr_array(params), z_in.data_ptr(),
+                                              pc.data_ptr() if pc is not None else None, B, h, w, int(T), z_pred.data_ptr(),
                                               ws.data_ptr(), ws.numel(), self._stream(z_in)), "lns_train_forward")
         return z_pred, ws
 

@@ -557,8 +557,7 @@ def test_metric_matches_reference_golden(name):
 def test_teacher_forced_loss_matches_oracle(preset):
     """LatentDynamics.forward(z_in, z_out[, param], loss_fn): loss value of the latent rollout against pre-encoded
     targets (train_stage2_ns2d.py:126-141), vs the oracle.  With autograd enabled the unconditional model runs the HIP
-    training rollout (same loss, differentiable: test_training_rollout_*); the conditional one, which has no HIP
-    backward yet, must raise rather than return a loss that silently carries no gradient."""
+    training rollout (same loss, differentiable: test_training_rollout_*), plain and conditional."""
     _need_gpu()
     import gpu_checks as gc
     import lns_oracle
@@ -577,12 +576,8 @@ def test_teacher_forced_loss_matches_oracle(preset):
     with torch.no_grad():
         loss = model(zi, zo, *extra, F.smooth_l1_loss)
     assert abs(float(loss) - ref) <= 2e-5 * abs(ref), (float(loss), ref)
-    if param is not None:
-        with pytest.raises(NotImplementedError):
-            model(zi, zo, *extra, F.smooth_l1_loss)
-    else:
-        lt = model(zi, zo, F.smooth_l1_loss)
-        assert lt.requires_grad and abs(float(lt) - ref) <= 2e-5 * abs(ref), (float(lt), ref)
+    lt = model(zi, zo, *extra, F.smooth_l1_loss)
+    assert lt.requires_grad and abs(float(lt) - ref) <= 2e-5 * abs(ref), (float(lt), ref)
 
 
 @pytest.mark.gpu
@@ -693,7 +688,7 @@ def test_packed_fp32_corun():
 
 
 # ---- the latent TRAINING rollout, forward + backward through time on the HIP engine ---------------------
-GRAD_CASES = ["ns2d_mini", "twophase", "sw_half_periodic"]
+GRAD_CASES = ["ns2d_mini", "twophase", "sw_half_periodic", "twophase_cond"]
 GRAD_TOL = 1e-4          # rel-L2 per parameter tensor against the REAL reference's loss.backward()
 
 
@@ -709,7 +704,10 @@ def _grad_setup(case):
     c, h, w = meta["latent"]
     z_in = torch.from_numpy(filler.normal("z_in", (B, 1, c, h, w), meta["input_seed"]) * np.float32(meta["z_scale"])).cuda()
     z_out = torch.from_numpy(filler.normal("z_out", (B, T, c, h, w), meta["input_seed"]) * np.float32(meta["z_scale"])).cuda()
-    return g, meta, model, z_in, z_out, F.smooth_l1_loss
+    if args.family == "twophase_cond":       # forward(z_in, z_out, param, loss_fn)
+        prm = torch.from_numpy(filler.uniform01("param", B, meta["input_seed"]).astype(np.float32)).cuda()
+        return g, meta, model, z_in, z_out, (prm, F.smooth_l1_loss)
+    return g, meta, model, z_in, z_out, (F.smooth_l1_loss,)
 
 
 @pytest.mark.parametrize("case", GRAD_CASES)
@@ -718,16 +716,16 @@ def test_training_rollout_gradients_match_reference(case):
     213-215) on the HIP engine: loss, z_pred, every propagator parameter's gradient and the gradient of z_in against the
     REAL reference's (tools/make_golden.py grads), circular / zero / half-periodic padding, dilation 2 and 3."""
     _need_gpu()
-    g, meta, model, z_in, z_out, loss_fn = _grad_setup(case)
+    g, meta, model, z_in, z_out, tail = _grad_setup(case)
     for p_ in model._ae.parameters():
         p_.requires_grad_(False)
     z_in.requires_grad_(True)
-    loss = model(z_in, z_out, loss_fn)
+    loss = model(z_in, z_out, *tail)
     loss.backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - float(g["loss"])) <= 2e-6 * abs(float(g["loss"])) + 1e-7, (loss.item(), float(g["loss"]))
     with torch.no_grad():
-        zp = model._engine(z_in).rollout_latent(z_in[:, 0].contiguous(), meta["T"], to_x=False)[0]
+        zp = model._engine(z_in).rollout_latent(z_in[:, 0].contiguous(), meta["T"], param=tail[0] if len(tail) == 2 else None, to_x=False)[0]
     assert rel_l2(zp.cpu().numpy(), g["z_pred"]) < 2e-5
     params = dict(model.named_parameters())
     sub = meta["sub"]
@@ -755,7 +753,7 @@ def test_training_rollout_properties():
     the loss along a random direction in parameter space; an optimiser step changes the next loss (parameters are read
     from their device tensors at every call)."""
     _need_gpu()
-    g, meta, model, z_in, z_out, loss_fn = _grad_setup("ns2d_mini")
+    g, meta, model, z_in, z_out, (loss_fn,) = _grad_setup("ns2d_mini")
     for p_ in model._ae.parameters():
         p_.requires_grad_(False)
     names = [k for k in meta["keys"]]

@@ -13,11 +13,13 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 args, model, sd = bench.build_model(preset, torch.device("cuda", 0))
 x = torch.from_numpy(filler.normal("x", (B, args.in_channels, args.Ly, args.Lx), 5)).cuda()
+import numpy as np
+param = torch.from_numpy(filler.uniform01("p", B, 5).astype(np.float32)).cuda() if args.family == "twophase_cond" else None
 eng = model._engine(x)
-eng.rollout(x, 2, to_x=True)
+eng.rollout(x, 2, param=param, to_x=True)
 torch.cuda.synchronize()
 eng.timing_enable(True)
-eng.rollout(x, T, to_x=True)
+eng.rollout(x, T, param=param, to_x=True)
 torch.cuda.synchronize()
 tm = eng.timing()
 tot = sum(v["ms"] for v in tm.values())

@@ -224,7 +224,8 @@ def add_ensembles(which):
 # fp32 and fp64.  Stored per propagator parameter: the L2 norm of its gradient and every `sub`-th element (the D = 128
 # models have 1.3 M propagator parameters), plus the loss, z_pred and the gradient w.r.t. z_in.
 # ---------------------------------------------------------------------------------------------------------------
-GRAD_CASES = {"ns2d_mini": ("ns2d_mini", 4, 3), "twophase": ("twophase", 3, 37), "sw_half_periodic": ("sw_half_periodic", 2, 37)}
+GRAD_CASES = {"ns2d_mini": ("ns2d_mini", 4, 3), "twophase": ("twophase", 3, 37), "sw_half_periodic": ("sw_half_periodic", 2, 37),
+              "twophase_cond": ("twophase_cond", 3, 37)}
 
 
 def make_grad_goldens(which=None):
@@ -248,12 +249,25 @@ def make_grad_goldens(which=None):
             z_out = torch.from_numpy(filler.normal("z_out", (B, T, c, h, w), INPUT_SEED) * np.float32(0.5)).to(dt)
             for p_ in ae.parameters():
                 p_.requires_grad_(False)
-            loss = model(z_in, z_out, F.smooth_l1_loss)
+            pt = None
+            if args.family == "twophase_cond":
+                pt = torch.from_numpy(filler.uniform01("param", B, INPUT_SEED).astype(np.float32)).to(dt)
+                if dt == torch.float64:        # cond_utils.fourier_embedding casts to fp32 (`.float()`, :34): re-cast for the fp64 run
+                    import ref_shim
+                    mod = ref_shim.load_reference()["train_stage2_twophase_conditional"]
+                    if not getattr(mod.fourier_embedding, "_lns_f64", False):
+                        orig = mod.fourier_embedding
+
+                        def fe64(t, dim, max_period=10000, _o=orig):
+                            return _o(t, dim, max_period).to(t.dtype)
+                        fe64._lns_f64 = True
+                        mod.fourier_embedding = fe64
+            loss = model(z_in, z_out, pt, F.smooth_l1_loss) if pt is not None else model(z_in, z_out, F.smooth_l1_loss)
             loss.backward()
             with torch.no_grad():
                 zp, z = [], z_in[:, 0]
                 for _ in range(T):
-                    z = model.propagator(z)
+                    z = model.propagator(z, pt) if pt is not None else model.propagator(z)
                     zp.append(z)
                 zp = torch.stack(zp, 1)
             out["loss" + tag] = np.float64(loss.item())

@@ -382,8 +382,10 @@ struct Planner {
             prod->conv.y == as_ptr<float>(x.ptr) && prod->conv.Cout == x.C && (long)x.H * x.W >= min_hw) {
             const ConvArgs& c = prod->conv;
             const int BW = 1 << c.bw_log2, BH = GN_TILE_PIXELS / BW;
-            const int tiles = c.tiles_x * c.tiles_y;
-            if (c.tiles_x * BW == x.W && c.tiles_y * BH == x.H && (size_t)B * tiles * x.C * 8 <= stat_cap) {
+            // (phase form of an upsampling conv: tiles are SOURCE tiles, each computed for four output phases)
+            const int um = c.up2 ? 2 : 1;
+            const int tiles = c.tiles_x * c.tiles_y * (c.up2 ? 4 : 1);
+            if (c.tiles_x * BW * um == x.W && c.tiles_y * BH * um == x.H && (size_t)B * tiles * x.C * 8 <= stat_cap) {
                 prod->conv.stat_part = as_ptr<float>(stat_scratch);
                 op.gn_tile_part = as_ptr<const float>(stat_scratch);
                 op.gn_tiles = tiles;
@@ -404,7 +406,12 @@ struct Planner {
                    int fuse_pack = -1, bool want_amax = true) {
         const ConvPack& pk = e->packs[pack_id];
         if (pk.cin != in.C) throw std::runtime_error(fmt("%s: input has %d channels, conv expects %d", name.c_str(), in.C, pk.cin));
-        const int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
+        int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
+        // 3x3 over an exactly 2x nearest-upsampled tensor: the phase-decomposed four-tap form (conv3_bf16x3_kernel, NTAP = 4)
+        // -- tiles, patch and maps are those of a plain pad-1 3x3 convolution of the SOURCE; a per-layer rule
+        const bool up2 = k == 3 && stride == 1 && dil == 1 && in.vH == 2 * in.H && in.vW == 2 * in.W && pk.has_wu && pk.f16 &&
+                         pad[0] == 1 && pad[1] == 1 && pad[2] == 1 && pad[3] == 1 && in.bounded() && pk.cout > 32;
+        if (up2) { Hv = in.H; Wv = in.W; }
         ConvGeom g;
         const bool thin_ok = !res && !badd && act_out == ACT_NONE && fuse_pack < 0 && !in.vH &&
                              (in.act == ACT_NONE || (in.act == ACT_SWISH && in.ss != 0));
@@ -413,12 +420,14 @@ struct Planner {
         if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0,
                            pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok))
             throw std::runtime_error("no conv tiling for " + name);
+        if (up2 && g.variant != CV_F64) throw std::runtime_error("phase form needs the f16x2 64-cout tiles: " + name);
+        if (up2) { g.Hout = 2 * in.H; g.Wout = 2 * in.W; }
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
         std::vector<int> rm, cm;
         if (k == 3) {
-            build_axis_map(rm, (g.tiles_y - 1) * BH * stride + g.PH, in.H, Hv, in.sch, pad[0], pad[1], my);
-            build_axis_map(cm, (g.tiles_x - 1) * BW * stride + g.PW, in.W, Wv, in.scw, pad[2], pad[3], mx);
+            build_axis_map(rm, (g.tiles_y - 1) * BH * stride + g.PH, in.H, Hv, up2 ? 0.0f : in.sch, pad[0], pad[1], my);
+            build_axis_map(cm, (g.tiles_x - 1) * BW * stride + g.PW, in.W, Wv, up2 ? 0.0f : in.scw, pad[2], pad[3], mx);
         } else if (in.vH) throw std::runtime_error("1x1 conv of a resized tensor is not supported: " + name);
         TRef out;
         if (out_forced) out = *out_forced;
@@ -434,7 +443,8 @@ struct Planner {
         memset(&a, 0, sizeof a);
         a.x = as_ptr<const float>(in.ptr); a.x_bs = in.bs; a.Cin = in.C; a.Hin = in.H; a.Win = in.W;
         a.w = as_ptr<const float>(wt(pk.w_off));
-        if (g.variant >= CV_B64) a.wb = as_ptr<const void>(wt(pk.wb_off));   // CV_B32 included
+        if (g.variant >= CV_B64) a.wb = as_ptr<const void>(wt(up2 ? pk.wu_off : pk.wb_off));   // CV_B32 included
+        a.up2 = up2 ? 1 : 0;
         if (g.variant == CV_B1 && pk.Cin_pad <= 64 && g.cout_tiles >= 2 && fuse_pack < 0) {
             // input-stationary form; the number of cout tiles per block only changes the launch shape, never a bit
             static const bool off = getenv("LNS_CONV1_NO_STATIONARY") != nullptr;
@@ -457,7 +467,7 @@ struct Planner {
         if (res) { a.res = as_ptr<const float>(res->ptr); a.res_bs = res->bs; }
         a.badd = as_ptr<const float>(badd);
         a.ks = k; a.stride = stride; a.dil = dil;
-        a.unscale = (cv_is_f16x2_3x3(g.variant) || g.variant == CV_B1) ? 1.0f / pk.wscale : 1.0f;   // x 1/S in the kernel
+        a.unscale = (cv_is_f16x2_3x3(g.variant) || g.variant == CV_B1) ? 1.0f / (up2 ? pk.wscale_up : pk.wscale) : 1.0f;   // x 1/S in the kernel
         if (in.ss != 0 && in.gn_bound > 0.0f) { a.amax_in_const = in.gn_bound; a.bound_final = 1; }   // GroupNorm output: layer constant
         else {
             a.amax_in = as_ptr<const unsigned>(in.amax); a.amax_in_const = in.amax_const;
@@ -1008,6 +1018,9 @@ static int finalize_weights(lns_engine* e, int device) {
             p.wb_off = off;
             off += round_up_sz((p.k == 3 ? convb_weight_bytes(p.cout, p.Cin_pad) : convb1_weight_bytes(p.cout, p.Cin_pad)) / 4, 64);
         }
+        static const bool no_up2 = getenv("LNS_NO_UP2_PHASES") != nullptr;       // A/B knob: the nine-tap gather form everywhere
+        p.has_wu = p.up2 && p.has_wb && p.k == 3 && !no_up2;
+        if (p.has_wu) { p.wu_off = off; off += round_up_sz(convu_weight_bytes(p.cout, p.Cin_pad) / 4, 64); }
     }
     for (VecPack& v : e->vecs) { v.off = off; off += round_up_sz(v.count, 64); }
     std::vector<float> host(off, 0.0f);
@@ -1024,6 +1037,7 @@ static int finalize_weights(lns_engine* e, int device) {
         if (!(mx > 0.0f) || !std::isfinite(mx)) { if (p.k == 1) p.wscale = 1.0f; continue; }   // all-zero weights: scale 1 (3x3: bf16x3)
         p.f16 = p.k == 3;
         p.wscale = exp2f(floorf(log2f(16000.0f / mx)));
+        p.wscale_up = p.wscale * 0.25f;          // a phase tap sums up to four taps: keep the fp16 high term below 2^14 as well
     }
     for (const ConvPack& p : e->packs) {
         int co = 0;
@@ -1032,6 +1046,7 @@ static int finalize_weights(lns_engine* e, int device) {
             pack_conv_weight(host.data() + p.w_off, w.host.data(), co, p.couts[i], p.cin, p.k, p.Cin_pad, p.Cout_pad);
             if (p.has_wb && p.k == 3 && !p.f16) convb_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad);
             if (p.has_wb && p.k == 3 && p.f16) convf_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad, p.wscale);
+            if (p.has_wu && p.f16) convu_pack_weight(host.data() + p.wu_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad, p.wscale_up);
             if (p.has_wb && p.k == 1) convb1_pack_weight(host.data() + p.wb_off, w.host.data(), co, p.couts[i], p.cin, p.Cin_pad, p.wscale);
             if (!p.bkeys[i].empty()) {
                 const Param& b = e->params[e->pindex.at(p.bkeys[i])];
@@ -1938,6 +1953,11 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     OPCHK(init_kernels());
     const bool stationary = tile_variant == 8;      // test code: 1x1 bf16x3 kernel in its input-stationary form
     if (stationary) tile_variant = CV_B1;
+    const bool up2 = tile_variant == 17;            // test code: f16x2 3x3 kernel, phase form of an exactly-2x nearest upsample
+    if (up2) {
+        if (ksize != 3 || stride != 1 || dilation != 1 || Hv != 2 * Hin || Wv != 2 * Win || pad_t != 1 || pad_b != 1 || pad_l != 1 || pad_r != 1) return LNS_EINVAL;
+        tile_variant = CV_F64; Hv = Hin; Wv = Win;
+    }
     ConvPack pk;
     pk.cin = Cin; pk.cout = Cout; pk.k = ksize;
     pk.kc_log2 = ksize == 3 ? 3 : 5;
@@ -1956,6 +1976,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     const ConvVariantInfo vi = conv_variant_info(g.variant);
     const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
     std::vector<int> rm, cm;
+    if (up2) { g.Hout = 2 * Hin; g.Wout = 2 * Win; }
     const float sch = (Hv == 2 * Hin) ? 0.5f : 0.0f, scw = (Wv == 2 * Win) ? 0.5f : 0.0f;
     build_axis_map(rm, (g.tiles_y - 1) * BH * stride + g.PH, Hin, Hv, sch, pad_t, pad_b, mode_y);
     build_axis_map(cm, (g.tiles_x - 1) * BW * stride + g.PW, Win, Wv, scw, pad_l, pad_r, mode_x);
@@ -1968,12 +1989,14 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
         float mx = 0.0f;
         for (size_t i = 0; i < (size_t)Cout * Cin * ksize * ksize; ++i) mx = std::max(mx, fabsf(w_host[i]));
         if (mx > 0.0f) wscale = exp2f(floorf(log2f(16000.0f / mx)));
+        if (up2) wscale *= 0.25f;
     }
-    const size_t wb_floats = cv_is_split_3x3(g.variant) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
+    const size_t wb_floats = up2 ? convu_weight_bytes(Cout, pk.Cin_pad) / 4 : cv_is_split_3x3(g.variant) ? convb_weight_bytes(Cout, pk.Cin_pad) / 4
                            : g.variant == CV_B1 ? convb1_weight_bytes(Cout, pk.Cin_pad) / 4 : 0;
     if (wb_floats) {
         hw.resize(hw.size() + wb_floats, 0.0f);
-        if (cv_is_f16x2_3x3(g.variant)) convf_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
+        if (up2) convu_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
+        else if (cv_is_f16x2_3x3(g.variant)) convf_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
         else if (g.variant != CV_B1) convb_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad);
         else convb1_pack_weight(hw.data() + wcount + pk.Cout_pad, w_host, 0, Cout, Cin, pk.Cin_pad, wscale);
     }
@@ -1993,6 +2016,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;
     a.ks = ksize; a.stride = stride; a.dil = dilation; a.Cin_pad = pk.Cin_pad; a.Cout_pad = pk.Cout_pad;
     a.unscale = (cv_is_f16x2_3x3(g.variant) || g.variant == CV_B1) ? 1.0f / wscale : 1.0f;
+    a.up2 = up2 ? 1 : 0;
     // the input's per-sample maximum, as the producing kernel of a plan would have recorded it
     OPCHK(hipMalloc(reinterpret_cast<void**>(&oc.damax), (size_t)B * LNS_AMAX_SUB * 4));
     // (on the CALLER's stream: x may still be being produced there, and a non-blocking stream does not order with the

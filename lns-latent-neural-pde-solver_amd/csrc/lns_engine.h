@@ -30,6 +30,8 @@ struct ConvPack {
     size_t w_off = 0, b_off = 0;      // float offsets in the device weight blob
     size_t wb_off = 0; bool has_wb = false;   // bf16x3 / f16x2 slabs
     bool f16 = false; float wscale = 1.0f;    // 3x3: slabs hold the two-term fp16 split of w * wscale
+    // the conv follows a 2x nearest upsample (UpSampleBlock, final nn.Upsample): phase slabs of the four-tap form too
+    bool up2 = false; size_t wu_off = 0; bool has_wu = false; float wscale_up = 1.0f;
 };
 
 enum VecXform { VX_NONE = 0, VX_TRANSPOSE2D = 1, VX_PE_T = 2 };

@@ -47,6 +47,10 @@ struct ConvArgs {
     // layout [cout tile][stage of 8 ch][split 3][tap 9][64 cout][8 ch]
     const void* wb;
     float unscale;         // accumulator scale of the bf16x3 / f16x2 epilogue: 1, or 1 / (16 * weight scale) for the fp16 form
+    // 1: `wb` holds the PHASE slabs of a 3x3 convolution applied to the 2x nearest-upsampled input (convu_pack_weight):
+    // x is the SOURCE tensor, tiles / patch / maps are those of a plain pad-1 3x3 convolution of the source, and
+    // Hout = 2 Hin, Wout = 2 Win; every block computes 128 source pixels of one of the four output phases (f16x2 kernel)
+    int up2;
     int ct_per_block;      // 1x1 bf16x3, input-stationary form: cout tiles walked by one block (0 = streaming form)
     // 3x3 split-operand kernel, 128-pixel tiles that cover the plane exactly: per (sample, pixel tile, channel)
     // (mean, centred second moment) of the stored output, [B][tiles][Cout][2]; the following GroupNorm merges them
@@ -115,6 +119,8 @@ hipError_t launch_conv_pc(int nt, const ConvArgs& a, hipStream_t s);
 size_t convb_weight_bytes(int Cout, int Cin_pad);
 void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);
 void convf_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale);   // f16x2 slabs
+size_t convu_weight_bytes(int Cout, int Cin_pad);                                                          // phase slabs (ConvArgs::up2)
+void convu_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale);
 // 1x1 bf16x3 kernel: slabs [cout tile][stage of 32 ch][split 3][octet 4][64 cout][8 ch], Cin_pad % 32 == 0
 size_t convb1_lds_bytes(const ConvArgs& a);
 bool convb1_fits(const ConvArgs& a);

@@ -774,7 +774,8 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 template <int NT, bool FUSE2, int MT = 2>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
-                                               float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1, long long* ets = nullptr) {
+                                               float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1, long long* ets = nullptr,
+                                               int tile_mult = 1) {
     constexpr int TM = 32 * MT, NTHR = 256;      // ct counts TM-wide cout tiles
     static_assert(!FUSE2 || MT == 2, "the fused second 1x1 needs all 64 channels of a pixel in one wave");
     // fused second conv: its weights are requested first, so that their L2 latency hides behind the first conv's epilogue
@@ -1097,15 +1098,21 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
         }
         const int co = ct * TM + c;
         if (q == 0 && co < a.Cout) {
-            const int tile = sp_tile >= 0 ? sp_tile : (int)blockIdx.x / a.cout_tiles, ntiles = a.tiles_x * a.tiles_y;
+            const int tile = sp_tile >= 0 ? sp_tile : (int)blockIdx.x / a.cout_tiles, ntiles = a.tiles_x * a.tiles_y * tile_mult;
             float* pp = a.stat_part + (((long)b * ntiles + tile) * a.Cout + co) * 2;
             pp[0] = mean; pp[1] = m2;
         }
     }
 }
 
-template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3>
+template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3, int NTAP = 9>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
+    // NTAP = 4: the 3x3 convolution of a 2x nearest-upsampled tensor, PHASE-DECOMPOSED.  Output pixel (2i + pa, 2j + pb)
+    // only sees the 2 x 2 source neighbourhood rows {i-1+pa, i+pa} x columns {j-1+pb, j+pb}, with the 3x3 taps that
+    // fall on the same source pixel summed on the host (pa = 0: rows {ky 0 | ky 1+2}, pa = 1: {ky 0+1 | ky 2}; columns
+    // alike): 4 taps = two K = 16 MFMA steps per 8-channel stage instead of five (nine taps padded to ten) -- 2.5x
+    // fewer matrix instructions for the same layer.  A block computes 128 SOURCE pixels of one phase; the patch is the
+    // source-resolution halo patch (maps of a plain pad-1 3x3 convolution of the source), the slab is the phase's.
     // (Two accumulators per tile -- hh' apart from hl' + lh' -- are part of the accuracy here: with all three products in
     //  one fp32 accumulator the 64-step NS2d rollout is at 1.0e-4 of the reference instead of 2.7e-5 ... 4.8e-5, and three
     //  blocks per CU at 168 registers spill; measured, not adopted.  The 1x1 kernels, K <= 512, do use one: CONVB1_ONEACC.)
@@ -1114,8 +1121,10 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // dropped ll' term is <= 2^-24 |xy|.  Half the MFMAs and 2/3 of the LDS bytes at the accuracy of an fp32 chain.
     // MT = 1: 32-cout tiles (half a weight slab per block).  Same accumulation order, so the planner may pick it
     // freely; it is used when 64-cout tiles would leave CUs with fewer than two blocks.
-    constexpr int NTHR = 256, TM = 32 * MT, TN = 128 * NT, KC = 8, NJ = 5;
-    constexpr int SLAB64 = CONVB_SLAB_BYTES * SPL / 3;    // host slab of a 64-cout tile, one stage
+    constexpr int NTHR = 256, TM = 32 * MT, TN = 128 * NT, KC = 8, NJ = (NTAP + 1) / 2;
+    constexpr bool UP2 = NTAP == 4;
+    static_assert(NTAP == 9 || (NTAP == 4 && SPL == 2 && MT == 2), "phase form: f16x2, 64-cout tiles");
+    constexpr int SLAB64 = SPL * NTAP * 64 * 16;          // host slab of a 64-cout tile, one stage (one phase)
     constexpr int SLAB = SLAB64 * MT / 2;                 // bytes of weights per stage in LDS
     constexpr int NWU = (SLAB / 16 + NTHR - 1) / NTHR;    // weight 16-byte units per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1136,6 +1145,9 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     int bid = blockIdx.x;
     const int ct = bid % a.cout_tiles;
     bid /= a.cout_tiles;
+    int phase = 0;
+    if (UP2) { phase = bid & 3; bid >>= 2; }
+    const int pa = phase >> 1, pb = phase & 1;
     const int tx = bid % a.tiles_x, ty = bid / a.tiles_x;
     const int BW = 1 << a.bw_log2, BH = TN >> a.bw_log2;
     const int HWin = a.Hin * a.Win;
@@ -1178,8 +1190,9 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     float xinv = 1.0f;
     // weight slab of this cout tile: host slabs hold 64 couts per (split, tap) row; a 32-cout block copies its half
     // of every row.  16 bytes per thread-slot.
-    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * SLAB64 +
-                        (MT == 1 ? (ct & 1) * 512 : 0);
+    const long wstage = UP2 ? 4L * SLAB64 : SLAB64;    // phase form: [cout tile][stage][phase] slabs
+    const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * wstage +
+                        (UP2 ? (long)phase * SLAB64 : 0) + (MT == 1 ? (ct & 1) * 512 : 0);
 
     // per-lane operand offsets (bytes).  K of one MFMA = 2 taps x 8 channels: lane half kh takes tap 2j+kh.
     // The 10th tap does not exist: in k-step 4 the kh=1 lanes multiply the shared zero unit with tap 8's
@@ -1193,11 +1206,11 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int t = 2 * j + kh;
-        const int tc = t < 9 ? t : 8;
-        ltoff[j] = (((tc / 3) * a.dil) * PW + (tc % 3) * a.dil) * 16;
+        const int tc = t < NTAP ? t : NTAP - 1;
+        ltoff[j] = UP2 ? (((tc >> 1) + pa) * PW + (tc & 1) + pb) * 16 : (((tc / 3) * a.dil) * PW + (tc % 3) * a.dil) * 16;
         aoff[j] = (tc * TM + l31) * 16;
     }
-    const bool ztap = kh != 0;                          // k-step 4: this lane half reads the zero unit
+    const bool ztap = kh != 0;                          // nine taps: in k-step 4 this lane half reads the zero unit
 
     f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
 #pragma unroll
@@ -1259,7 +1272,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         const int idx = tid + i * NTHR;                  // 16-byte unit inside the slab
         const int off = idx < SLAB / 16 ? idx : SLAB / 16 - 1;
         const int src = MT == 1 ? (off >> 5) * 1024 + (off & 31) * 16 : off * 16;     // row of 64 couts -> its 32
-        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * SLAB64 + src);
+        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * wstage + src);
         wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
     };
     auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
@@ -1275,11 +1288,11 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         for (int s = 0; s < SPL; ++s) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                af[s][mt] = *reinterpret_cast<const uint4*>(Ws + s * (9 * TM * 16) + mt * (32 * 16) + aoff[j]);
+                af[s][mt] = *reinterpret_cast<const uint4*>(Ws + s * (NTAP * TM * 16) + mt * (32 * 16) + aoff[j]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const char* p = Xs + s * PP1 * 16 + boff[nt] + ltoff[j];
-                if (j == NJ - 1) p = ztap ? zunit : p;
+                if (j == NJ - 1 && (NTAP & 1)) p = ztap ? zunit : p;
                 bf[s][nt] = *reinterpret_cast<const uint4*>(p);
             }
         }
@@ -1352,7 +1365,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                 // this k-step transforms pair j of stage cw with the table entries read one k-step ago; the entries of
                 // the next pair to be transformed (pair j+1, or pair 0 of the following stage) are requested now
                 const float4 stu = stq;
-                if (MODE >= 1 && j != 3) stq = *reinterpret_cast<const float4*>(ssl + 2 * (j < 3 ? cw + 2 * (j + 1) : cl2));
+                if (!UP2 && MODE >= 1 && j != 3) stq = *reinterpret_cast<const float4*>(ssl + 2 * (j < 3 ? cw + 2 * (j + 1) : cl2));
                 auto& A = af[j & 1];
                 auto& Bq = bf[j & 1];
                 // product-major order: consecutive MFMAs belong to different accumulators
@@ -1376,7 +1389,25 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                     LNS_BX3(acc_lo, 1, 0)
                 }
 #undef LNS_BX3
-                if (j < 4) {
+                if (UP2) {       // two k-steps per stage: two channel pairs and half of the (small) slab each
+#pragma unroll
+                    for (int u = 0; u < NU; ++u)
+#pragma unroll
+                        for (int cp = 2 * j; cp < 2 * j + 2; ++cp) {
+                            split_pair(mode_tag, u, cp, cw);
+                            load_pair(u, cp, cl2);
+                        }
+#pragma unroll
+                    for (int i = j * ((NWU + 1) / 2); i < (j + 1) * ((NWU + 1) / 2); ++i)
+                        if (i < NWU) {
+                            write_w(i, Wn);
+                            load_w(i, cl2);
+                        }
+                    if (j == NJ - 1) {
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) flush_unit(u, Xn);
+                    }
+                } else if (j < 4) {
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
                         split_pair_r(mode_tag, u, j, stu);
@@ -1417,13 +1448,15 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
-        const int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
+        int oy = ty * BH + (p >> a.bw_log2), ox = tx * BW + (p & (BW - 1));
+        if (UP2) { oy = 2 * oy + pa; ox = 2 * ox + pb; }     // source pixel -> this phase's output pixel
         pix[nt] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : -1;
     }
     unsigned am = 0u;
     LNS_TSTAMP(3)
     convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am,
-                                  (a.bias || a.badd) ? addv : nullptr, -1 LNS_ETS_ARG);
+                                  (a.bias || a.badd) ? addv : nullptr, UP2 ? (ty * a.tiles_x + tx) * 4 + phase : -1 LNS_ETS_ARG,
+                                  UP2 ? 4 : 1);
     LNS_TSTAMP(4)
     if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);    // wmax: free since the prologue
     LNS_TS_DUMP
@@ -1925,7 +1958,10 @@ hipError_t launch_conv1_bf16x3(const ConvArgs& a, hipStream_t s) {
 
 size_t convb_lds_bytes(const ConvArgs& a, int tm, int spl, int ring) {
     const size_t pp1 = (size_t)a.PH * a.PW + 1;
-    return ring * (spl * pp1 * 16 + (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64) + 16 + ((size_t)a.Cin_pad * 2 + 64) * 4 + 16 + 16;
+    const size_t slab = a.up2 ? (size_t)spl * 4 * 64 * 16 : (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64;
+    // the epilogue reuses the stage buffers: GroupNorm tile statistics need 64 x 133 floats, the fused 1x1 conv its weights
+    const size_t stage = std::max(ring * (spl * pp1 * 16 + slab), (size_t)64 * 133 * 4 + 64);
+    return stage + 16 + ((size_t)a.Cin_pad * 2 + 64) * 4 + 16 + 16;
 }
 
 bool convb_fits(const ConvArgs& a) {
@@ -1990,6 +2026,38 @@ void convf_pack_weight(void* dst, const float* w, int co0, int cout, int cin, in
                     d[(unit * 64 + cl) * 8 + c] = q[sidx];
                 }
             }
+        }
+    }
+}
+
+// Phase slabs of the 2x-upsample form: [cout tile][stage][phase pa*2+pb][split 2][tap ty*2+tx][cout 64][8 ch] fp16; the taps
+// of the 3x3 kernel that fall on the same source pixel are summed (in double) before the scale and the split.
+size_t convu_weight_bytes(int Cout, int Cin_pad) { return (size_t)((Cout + 63) / 64) * (Cin_pad / 8) * 4 * (2 * 4 * 64 * 16); }
+void convu_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad, float wscale) {
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    const int nstage = Cin_pad / 8;
+    static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};      // [phase bit][tap bit]: ky range
+    for (int co = 0; co < cout; ++co) {
+        const int cog = co0 + co, ct = cog / 64, cl = cog % 64;
+        for (int ci = 0; ci < cin; ++ci) {
+            const int st = ci / 8, c = ci % 8;
+            const float* wk = w + ((size_t)co * cin + ci) * 9;
+            for (int ph = 0; ph < 4; ++ph)
+                for (int t = 0; t < 4; ++t) {
+                    const int pa = ph >> 1, pb = ph & 1, ty = t >> 1, tx = t & 1;
+                    double sum = 0.0;
+                    for (int ky = lo[pa][ty]; ky <= hi[pa][ty]; ++ky)
+                        for (int kx = lo[pb][tx]; kx <= hi[pb][tx]; ++kx) sum += (double)wk[ky * 3 + kx];
+                    const float v = (float)sum * wscale;
+                    float hb, lb;
+                    uint16_t q[2];
+                    q[0] = host_f16_rne(v, &hb);
+                    q[1] = host_f16_rne(v - hb, &lb);
+                    for (int sidx = 0; sidx < 2; ++sidx) {
+                        const size_t unit = ((((size_t)ct * nstage + st) * 4 + ph) * 2 + sidx) * 4 + t;
+                        d[(unit * 64 + cl) * 8 + c] = q[sidx];
+                    }
+                }
         }
     }
 }
@@ -2092,6 +2160,19 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<2, 2, false, 2, 2>), grid, dim3(256), lds, s, a);
         return hipGetLastError();
     }
+    if (variant == CV_F64 && a.up2) {                     // phase-decomposed 2x nearest upsample + 3x3 (four taps per phase)
+        const size_t lds = convb_lds_bytes(a, 64, 2, 2);
+        dim3 gu(a.tiles_x * a.tiles_y * a.cout_tiles * 4, a.B);
+        if (a.w2) {
+            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true, 2, 2, 4>), gu, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true, 2, 2, 4>), gu, dim3(256), lds, s, a);
+        } else {
+            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 2, 2, 4>), gu, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 2, 2, 4>), gu, dim3(256), lds, s, a);
+        }
+        return hipGetLastError();
+    }
+    if (a.up2) return hipErrorInvalidValue;
     if (variant == CV_F64) {                              // two-term fp16 split
         const size_t lds = convb_lds_bytes(a, 64, 2, 2);
         if (a.w2) {
@@ -4532,6 +4613,10 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv1_bf16x3_kernel<false, true>))
     LNS_SET_LDS((conv1_bf16x3_kernel<false, false>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 2, 2>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 2, 2, 4>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2, 4>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true, 2, 2, 4>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true, 2, 2, 4>))
     LNS_SET_LDS((conv3_bf16x3_kernel<2, 2, false, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<2, 2, true, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2>))

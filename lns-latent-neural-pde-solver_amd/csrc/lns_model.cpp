@@ -383,6 +383,7 @@ static void build_decoder(Builder& b, const lns_config& c, std::vector<Layer>& L
             Layer u; u.type = LT_UP2; u.name = name(idx);
             L.push_back(u);
             L.push_back(same_conv(b, name(idx) + ".conv_layer", cin, cin, 3, my, mx));
+            b.e->packs[L.back().pack].up2 = true;       // (the planner takes the four-tap phase form when the resize is exactly 2x)
             ++idx;
             res *= 2;
         }
@@ -393,6 +394,7 @@ static void build_decoder(Builder& b, const lns_config& c, std::vector<Layer>& L
     }
     res = c.Ly;
     L.push_back(same_conv(b, name(idx), cin, cin, 3, my, mx)); ++idx;
+    b.e->packs[L.back().pack].up2 = true;
     if (c.final_smoothing) {
         L.push_back(fourier_layer(b, name(idx++), cin, cin, 16, sq ? 16 : (int)(16 * hw)));
     } else {

@@ -196,6 +196,14 @@ PC_CASES = [dict(B=2, Cin=64, Cout=64, H=32, W=32, mode=(1, 1)), dict(B=2, Cin=6
 for _c in PC_CASES:
     CONV_CASES.append(dict(k=3, variant=15, **_c))
     CONV_CASES.append(dict(k=3, variant=16, **_c))
+# phase-decomposed form of a 3x3 conv over an exactly 2x nearest-upsampled tensor (variant 17: four summed taps per
+# output phase, f16x2 kernel): every padding mode, prologue / epilogue features, ragged source tiles and cout tiles
+UP2_CASES = [dict(B=2, Cin=64, Cout=64, H=16, W=16, up=(32, 32), mode=(1, 1)), dict(B=2, Cin=64, Cout=64, H=16, W=16, up=(32, 32), mode=(0, 0)),
+             dict(B=2, Cin=64, Cout=64, H=12, W=24, up=(24, 48), mode=(0, 1)), dict(B=2, Cin=128, Cout=128, H=16, W=16, up=(32, 32), mode=(1, 1), ss=True, act_in=1, res=True),
+             dict(B=2, Cin=64, Cout=100, H=10, W=20, up=(20, 40), mode=(0, 0), act_out=2, badd=True),
+             dict(B=3, Cin=64, Cout=64, H=32, W=32, up=(64, 64), mode=(1, 1), bias=False), dict(B=1, Cin=40, Cout=64, H=7, W=15, up=(14, 30), mode=(0, 0), ss=True)]
+for _c in UP2_CASES:
+    CONV_CASES.append(dict(k=3, variant=17, **_c))
 # bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel
 # counts, prologue and epilogue features
 for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, Cout=128, H=16, W=16),

@@ -409,8 +409,9 @@ struct Planner {
         int Hv = in.vH ? in.vH : in.H, Wv = in.vW ? in.vW : in.W;
         // 3x3 over an exactly 2x nearest-upsampled tensor: the phase-decomposed four-tap form (conv3_bf16x3_kernel, NTAP = 4)
         // -- tiles, patch and maps are those of a plain pad-1 3x3 convolution of the SOURCE; a per-layer rule
+        static const bool fp32_only = getenv("LNS_CONV_FP32_MFMA") != nullptr;     // (strict-fp32 runs: no split-operand kernels)
         const bool up2 = k == 3 && stride == 1 && dil == 1 && in.vH == 2 * in.H && in.vW == 2 * in.W && pk.has_wu && pk.f16 &&
-                         pad[0] == 1 && pad[1] == 1 && pad[2] == 1 && pad[3] == 1 && in.bounded() && pk.cout > 32;
+                         pad[0] == 1 && pad[1] == 1 && pad[2] == 1 && pad[3] == 1 && in.bounded() && pk.cout > 32 && !fp32_only;
         if (up2) { Hv = in.H; Wv = in.W; }
         ConvGeom g;
         const bool thin_ok = !res && !badd && act_out == ACT_NONE && fuse_pack < 0 && !in.vH &&

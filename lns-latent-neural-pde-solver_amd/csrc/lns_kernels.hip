@@ -1143,10 +1143,26 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     const int l31 = lane & 31, kh = lane >> 5;
     const int b = blockIdx.y;
     int bid = blockIdx.x;
-    const int ct = bid % a.cout_tiles;
-    bid /= a.cout_tiles;
-    int phase = 0;
-    if (UP2) { phase = bid & 3; bid >>= 2; }
+    int ct, phase = 0;
+    if (UP2) {
+        // XCD-aware order: blocks g, g + 8, g + 16, ... share an XCD (and its L2), so the four phases (x cout tiles) of one
+        // source tile are made consecutive WITHIN an XCD: they read the same source patch (one HBM fetch instead of
+        // four) and their stride-2 stores complete each other's 128-byte lines in the same L2 (measured before: 271 MB
+        // fetched and 541 MB written per launch of the fused 128^2 layer, for 67 MB of input and 268 MB of output)
+        // Only when the sample's tiles fill whole groups of 8 (else most XCDs would idle: 16 x 16 sources have 2 tiles).
+        if (((a.tiles_x * a.tiles_y) & 7) == 0) {
+            const int x = bid & 7, q = bid >> 3, per = 4 * a.cout_tiles;
+            const int inner = q % per;
+            ct = inner % a.cout_tiles; phase = inner / a.cout_tiles;
+            bid = (q / per) * 8 + x;
+        } else {
+            ct = bid % a.cout_tiles; bid /= a.cout_tiles;
+            phase = bid & 3; bid >>= 2;
+        }
+    } else {
+        ct = bid % a.cout_tiles;
+        bid /= a.cout_tiles;
+    }
     const int pa = phase >> 1, pb = phase & 1;
     const int tx = bid % a.tiles_x, ty = bid / a.tiles_x;
     const int BW = 1 << a.bw_log2, BH = TN >> a.bw_log2;

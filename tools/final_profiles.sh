@@ -2,10 +2,10 @@ set -o pipefail
 R=$PWD; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 # 1. bench lines
 timeout -k 10 500 python bench.py > $O/bench_main.log 2>$O/bench_main.err || { echo BENCH FAIL; tail -3 $O/bench_main.err; exit 1; }
-tail -1 $O/bench_main.log > $O/r02_bench_line.json
-timeout -k 10 300 python bench.py --rollout 256 --no-strict-fp32 --no-cpu-baseline > $O/b256.log 2>/dev/null && tail -1 $O/b256.log > $O/r02_bench_line_ns2d_T256.json
-timeout -k 10 300 python bench.py --preset sw_96x192x5 --no-strict-fp32 --no-cpu-baseline > $O/bsw.log 2>/dev/null && tail -1 $O/bsw.log > $O/r02_bench_line_sw_96x192x5.json
-timeout -k 10 300 python bench.py --preset twophase_cond --batch 32 --rollout 128 --no-strict-fp32 --no-cpu-baseline > $O/btp.log 2>/dev/null && tail -1 $O/btp.log > $O/r02_bench_line_twophase_cond.json
+tail -1 $O/bench_main.log > $O/r03_bench_line.json
+timeout -k 10 300 python bench.py --rollout 256 --no-strict-fp32 --no-cpu-baseline > $O/b256.log 2>/dev/null && tail -1 $O/b256.log > $O/r03_bench_line_ns2d_T256.json
+timeout -k 10 300 python bench.py --preset sw_96x192x5 --no-strict-fp32 --no-cpu-baseline > $O/bsw.log 2>/dev/null && tail -1 $O/bsw.log > $O/r03_bench_line_sw_96x192x5.json
+timeout -k 10 300 python bench.py --preset twophase_cond --batch 32 --rollout 128 --no-strict-fp32 --no-cpu-baseline > $O/btp.log 2>/dev/null && tail -1 $O/btp.log > $O/r03_bench_line_twophase_cond.json
 echo bench done
 cd /tmp && export TMPDIR=/tmp
 # 2. kernel stats: serial (the per-kernel roofline pass) and overlapped
@@ -22,9 +22,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 echo pmc done
 cd $R
-python3 tools/pmc_summary.py $O/r02_pmc.json $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_WAIT_ANY $O/pmc_SQ_ACTIVE_INST_VALU $O/pmc_SQ_LDS_BANK_CONFLICT > $O/pmc_summary.txt 2>&1
+python3 tools/pmc_summary.py $O/r03_pmc.json $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_WAIT_ANY $O/pmc_SQ_ACTIVE_INST_VALU $O/pmc_SQ_LDS_BANK_CONFLICT > $O/pmc_summary.txt 2>&1
 F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python3 tools/make_traffic_json.py $F $W $O/r02_traffic.json > $O/traffic.txt 2>&1
+python3 tools/make_traffic_json.py $F $W $O/r03_traffic.json > $O/traffic.txt 2>&1
 find $O -name "*kernel_stats.csv" | head; 
 # keep the merge small: drop raw traces
 find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*counter_collection.csv" -size +2M -delete

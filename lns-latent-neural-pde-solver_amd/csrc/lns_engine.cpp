@@ -262,6 +262,8 @@ struct TRef {
     uint64_t ss = 0; size_t ss_off = 0; bool ss_owned = false;
     int act = ACT_NONE;
     int vH = 0, vW = 0; float sch = 0, scw = 0;   // virtual nearest resize
+    int gn_lazy = -1;      // GroupNorm whose finalize op has not been emitted yet (index into Planner::lazy_ops): the consumer
+                           // convolution merges the producer's tile partials itself, or flush_gn() emits the op
     // bound on |raw values| for the split-operand consumers: per-sample running maximum recorded by the producer
     // (tagged pointer to [B] unsigned) or an analytic constant (LayerNorm / InstanceNorm outputs); neither: unknown
     uint64_t amax = 0; float amax_const = 0.0f;
@@ -286,13 +288,30 @@ struct Planner {
 
     // Scratch for GroupNorm partials written by convolution epilogues: allocated before any op so that it never
     // aliases a tensor (the producing conv writes it while its own inputs are still being read).
+    // A RING of four regions: with the finalize step folded into the consumer convolution (below) the partials of a
+    // tensor must survive until that consumer has run, while the consumer's own epilogue may already write the next
+    // tensor's partials -- never into the region its blocks are still reading.  A region is reused four producers later;
+    // if the GroupNorm it held has still not been consumed by then, the planner refuses (never a silent overwrite).
+    static constexpr int STAT_RING = 4;
+    uint64_t stat_ring[STAT_RING] = {0, 0, 0, 0};
+    int stat_holder[STAT_RING] = {-1, -1, -1, -1};     // lazy GroupNorm (index) whose partials live in the region, or -1
+    int stat_next = 0;
     uint64_t stat_scratch = 0;
     size_t stat_cap = 0;
     void init_stat_scratch() {
         static const bool off = getenv("LNS_GN_NO_FUSE") != nullptr;
         if (off) return;
         stat_cap = (size_t)B * 128 * e->cfg.Ly * e->cfg.Lx / GN_TILE_PIXELS * 8;   // C * H * W <= 128 * Ly * Lx
-        stat_scratch = tag(SP_WS, arena.alloc(stat_cap));
+        for (int i = 0; i < STAT_RING; ++i) stat_ring[i] = tag(SP_WS, arena.alloc(stat_cap));
+        stat_scratch = stat_ring[0];
+    }
+    uint64_t take_stat_region(const std::string& name, int lazy_index) {
+        const int r = stat_next;
+        stat_next = (stat_next + 1) % STAT_RING;
+        if (stat_holder[r] >= 0 && !lazy_done[stat_holder[r]] && !lazy_folded[stat_holder[r]])
+            throw std::runtime_error("GroupNorm partials ring exhausted at " + name);
+        stat_holder[r] = lazy_index;
+        return stat_ring[r];
     }
 
     // amax slots: one [B] unsigned vector per produced tensor, all in one region taken before any op (never aliased)
@@ -350,6 +369,14 @@ struct Planner {
         plan->ops.push_back(op);
     }
 
+    // GroupNorm fed by a convolution's tile partials: the finalize op is held back (lazy) so that a split-operand
+    // consumer can fold it into its prologue (ConvArgs::gn_part); anything else that reads the table flushes it first
+    std::vector<Op> lazy_ops;
+    std::vector<char> lazy_done, lazy_folded;
+    void flush_gn(const TRef& x) {
+        if (x.gn_lazy >= 0 && !lazy_done[x.gn_lazy]) { plan->ops.push_back(lazy_ops[x.gn_lazy]); lazy_done[x.gn_lazy] = 1; }
+    }
+
     // GroupNorm statistics of a materialised tensor -> pending (scale, shift) on it
     void emit_gn(TRef& x, int groups, float eps, int vg, int vb, uint64_t premul, const std::string& name) {
         if (x.pending()) throw std::runtime_error("GroupNorm input must be materialised: " + name);
@@ -371,25 +398,47 @@ struct Planner {
         // Fed by the 3x3 split-operand kernel right before it (nothing in between but traces), 128-pixel tiles
         // covering the plane exactly: the conv epilogue leaves per-tile (mean, M2) and this op only merges them.
         // Layer-static decision, so results do not depend on the batch.
-        static const long min_hw = getenv("LNS_GN_FUSE_MIN_HW") ? atol(getenv("LNS_GN_FUSE_MIN_HW")) : 1024;
+        // From 16 x 16 planes up (two 128-pixel tiles): below 1024 pixels the merge launch used to cost what the statistics
+        // launch cost, but the merge now happens inside the consumer convolution (no launch at all) whenever it can.
+        static const bool no_fold = getenv("LNS_GN_NO_FOLD") != nullptr;        // A/B knob: round 2's behaviour
+        static const long min_hw = getenv("LNS_GN_FUSE_MIN_HW") ? atol(getenv("LNS_GN_FUSE_MIN_HW")) : (no_fold ? 1024 : 256);
         Op* prod = nullptr;
         for (size_t i = plan->ops.size(); i-- > 0;) {
             if (plan->ops[i].type == OP_TRACE) continue;
             prod = &plan->ops[i];
             break;
         }
-        if (stat_scratch && !premul && prod && prod->type == OP_CONV && (prod->variant == CV_F64 || prod->variant == CV_B64) &&
+        // producers with the statistics epilogue: the split-operand 3x3 kernels and the streaming 1x1 kernel (not its
+        // input-stationary form, not with a fused second conv: its statistics would be taken of the wrong tensor... they
+        // are taken of what is stored, which is right -- but only the plain form is covered by tests)
+        const bool prod_ok = prod && prod->type == OP_CONV &&
+                             (prod->variant == CV_F64 || prod->variant == CV_B64 ||
+                              (prod->variant == CV_B1 && !no_fold && prod->conv.ct_per_block == 0 && !prod->conv.w2 && (x.H * x.W) % GN_TILE_PIXELS == 0));
+        if (stat_scratch && !premul && prod_ok &&
             prod->conv.y == as_ptr<float>(x.ptr) && prod->conv.Cout == x.C && (long)x.H * x.W >= min_hw) {
             const ConvArgs& c = prod->conv;
             const int BW = 1 << c.bw_log2, BH = GN_TILE_PIXELS / BW;
             // (phase form of an upsampling conv: tiles are SOURCE tiles, each computed for four output phases)
             const int um = c.up2 ? 2 : 1;
             const int tiles = c.tiles_x * c.tiles_y * (c.up2 ? 4 : 1);
-            if (c.tiles_x * BW * um == x.W && c.tiles_y * BH * um == x.H && (size_t)B * tiles * x.C * 8 <= stat_cap) {
-                prod->conv.stat_part = as_ptr<float>(stat_scratch);
-                op.gn_tile_part = as_ptr<const float>(stat_scratch);
+            // the 128-pixel tiles cover the plane exactly (1x1: tiles of 128 consecutive pixels)
+            const bool exact = c.ks == 1 ? (c.tiles_x * GN_TILE_PIXELS == x.H * x.W && c.tiles_y == 1)
+                                         : (c.tiles_x * BW * um == x.W && c.tiles_y * BH * um == x.H);
+            if (exact && (size_t)B * tiles * x.C * 8 <= stat_cap) {
+                // foldable into the consumer's prologue: few tiles, one group or power-of-two groups within a wave
+                const int cg = x.C / groups;
+                static const int fold_tiles = getenv("LNS_GN_FOLD_TILES") ? atoi(getenv("LNS_GN_FOLD_TILES")) : 2;
+                const bool foldable = !no_fold && tiles <= fold_tiles && x.C <= 512 && (groups == 1 || (cg <= 64 && (cg & (cg - 1)) == 0));
+                const int li = (int)lazy_ops.size();
+                lazy_done.push_back(0); lazy_folded.push_back(0);
+                const uint64_t region = take_stat_region(name, li);
+                prod->conv.stat_part = as_ptr<float>(region);
+                op.gn_tile_part = as_ptr<const float>(region);
                 op.gn_tiles = tiles;
                 op.bytes = 2.0 * B * tiles * x.C * 8;
+                lazy_ops.push_back(op);
+                if (foldable) { x.gn_lazy = li; return; }
+                lazy_done[li] = 1;                       // finalize right away (below)
             }
         }
         plan->ops.push_back(op);
@@ -457,6 +506,19 @@ struct Planner {
         }
         a.bias = pk.has_bias ? as_ptr<const float>(wt(pk.b_off)) : nullptr;
         a.ss = as_ptr<const float>(in.ss);
+        if (in.gn_lazy >= 0 && !lazy_done[in.gn_lazy]) {
+            // GroupNorm whose finalize step is still pending: the split-operand kernels merge the producer's tile partials in
+            // their own prologue (no launch); every other consumer gets the finalize op now
+            if (g.variant == CV_F64 || g.variant == CV_B1) {
+                const Op& lo = lazy_ops[in.gn_lazy];
+                a.ss = nullptr;
+                a.gn_part = lo.gn_tile_part; a.gn_tiles = lo.gn_tiles; a.gn_groups = lo.gn.groups; a.gn_eps = lo.gn.eps;
+                a.gn_gamma = lo.gn.gamma; a.gn_beta = lo.gn.beta;
+                lazy_folded[in.gn_lazy] = 1;
+            } else {
+                flush_gn(in);
+            }
+        }
         a.act_in = in.act; a.act_out = act_out;
         if (k == 3) {
             a.rowmap = as_ptr<const int>(const_ints(rm));
@@ -732,6 +794,7 @@ struct Planner {
     // materialise a pending GroupNorm scale/shift (+ activation) -- used where the consumer's
     // prologue cannot express it (GELU prologue of the conditional block)
     TRef emit_apply(TRef& x, int act, const std::string& name) {
+        flush_gn(x);
         TRef y = alloc_t(x.C, x.H, x.W);
         Op op;
         op.type = OP_APPLY; op.name = name; op.cls = CLS_MISC;
@@ -1215,7 +1278,7 @@ struct Runner {
                     ConvArgs a = op.conv;
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
                     fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B); fix(a.stat_part, B);
-                    fix(a.amax_in, B); fix(a.amax_out, B);
+                    fix(a.amax_in, B); fix(a.amax_out, B); fix(a.gn_part, B); fix(a.gn_gamma, B); fix(a.gn_beta, B);
                     if (a.y_bs < 0) {          // output handed in by the caller: may be addressed in two levels (step-batched decode)
                         const int sl = SP_EXT0 + (int)(-a.y_bs - 1);
                         a.y_bs2 = B.bs2[sl]; a.y_bdiv = B.bdiv[sl];
@@ -1223,7 +1286,7 @@ struct Runner {
                     if (a.x_bs < 0 && B.bdiv[SP_EXT0 + (int)(-a.x_bs - 1)]) B.bad = true;   // inputs are always plain
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
                     if (!all_untagged(a.x, a.w, a.bias, a.ss, a.rowmap, a.colmap, a.y, a.res, a.badd, a.w2, a.bias2, a.wb, a.stat_part,
-                                      a.amax_in, a.amax_out)) B.bad = true;
+                                      a.amax_in, a.amax_out, a.gn_part, a.gn_gamma, a.gn_beta)) B.bad = true;
                     if (B.bad) break;
 #ifdef LNS_TS
                     // diagnostic build: per-block phase timestamps of the layer named by $LNS_TS_LAYER, appended to $LNS_TS_FILE

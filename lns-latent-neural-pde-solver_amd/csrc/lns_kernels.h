@@ -51,6 +51,11 @@ struct ConvArgs {
     // x is the SOURCE tensor, tiles / patch / maps are those of a plain pad-1 3x3 convolution of the source, and
     // Hout = 2 Hin, Wout = 2 Win; every block computes 128 source pixels of one of the four output phases (f16x2 kernel)
     int up2;
+    // GroupNorm folded into this convolution's prologue (split-operand 3x3 / 1x1 kernels): instead of the finished
+    // (scale, shift) table `ss`, the per-(sample, 128-pixel tile, channel) (mean, M2) partials the PRODUCER's epilogue left
+    // ([B][gn_tiles][Cin][2], ConvArgs::stat_part of that launch) plus gamma / beta; every block of a sample merges them
+    // itself (same code, same order: same bits), which removes the statistics / finalize launch from the dependency chain
+    const float* gn_part; const float* gn_gamma; const float* gn_beta; int gn_tiles, gn_groups; float gn_eps;
     int ct_per_block;      // 1x1 bf16x3, input-stationary form: cout tiles walked by one block (0 = streaming form)
     // 3x3 split-operand kernel, 128-pixel tiles that cover the plane exactly: per (sample, pixel tile, channel)
     // (mean, centred second moment) of the stored output, [B][tiles][Cout][2]; the following GroupNorm merges them

@@ -137,7 +137,67 @@ __device__ __forceinline__ float f16x2_scale(unsigned bound_bits, float& inv) {
 // Block prologue shared by the split-operand kernels: stages this sample's GroupNorm (scale, shift) table into LDS
 // (identity for channels without one) and returns each wave's share of bound = max_c(|s_c| amax + |t_c|) through
 // wmax[wave] (4 words of LDS); after the block's next barrier block_bound() gives the block-wide value.
+// block-wide sum for blockDim.x == 256 through 4 floats of LDS (defined below)
+__device__ __forceinline__ float block_sum_256(float v, float* red);
+__device__ __forceinline__ float wave_sum(float v);
+
+// GroupNorm folded into the consumer (ConvArgs::gn_part): (scale, shift) of channel c from the producer's per-tile
+// partials.  groups == 1: two block-wide sums over all tiles x channels; otherwise (channels per group a power of two
+// <= 64) every thread sums its channel over the tiles and the group over its aligned lanes by xor shuffles.  Equal-count
+// merge (every partial covers 128 pixels), two-pass like gn_tile_finalize_kernel; all blocks of a sample run the same
+// code on the same data, so the table is bit-identical in all of them.  Called by all 256 threads; uses wmax as scratch.
+__device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid) {
+    const int C = a.Cin, tiles = a.gn_tiles;
+    const float* pb = a.gn_part + (long)b * tiles * C * 2;
+    float* red = reinterpret_cast<float*>(wmax);
+    if (a.gn_groups == 1) {
+        const int E = tiles * C;
+        float sm = 0.0f;
+        for (int i = tid; i < E; i += 256) sm += pb[2 * i];
+        const float mean = block_sum_256(sm, red) / (float)E;
+        float m2 = 0.0f;
+        for (int i = tid; i < E; i += 256) { const float d = pb[2 * i] - mean; m2 += pb[2 * i + 1] + 128.0f * d * d; }
+        const float var = block_sum_256(m2, red) / (128.0f * (float)E);
+        const float rstd = 1.0f / sqrtf(var + a.gn_eps);
+        for (int c = tid; c < a.Cin_pad; c += 256) {
+            float2 st = make_float2(1.0f, 0.0f);
+            if (c < C) {
+                const float ga = a.gn_gamma ? a.gn_gamma[c] : 1.0f, be = a.gn_beta ? a.gn_beta[c] : 0.0f;
+                st = make_float2(rstd * ga, be - mean * rstd * ga);
+            }
+            *reinterpret_cast<float2*>(ssl + 2 * c) = st;
+        }
+    } else {
+        const int cg = C / a.gn_groups;                    // power of two <= 64: a group is an aligned run of lanes
+        for (int c0 = 0; c0 < a.Cin_pad; c0 += 256) {
+            const int c = c0 + tid;
+            const bool live = c < C;
+            float sm = 0.0f;
+            if (live) for (int t = 0; t < tiles; ++t) sm += pb[((long)t * C + c) * 2];
+            for (int o = 1; o < cg; o <<= 1) sm += __shfl_xor(sm, o);
+            const float mean = sm / (float)(tiles * cg);
+            float m2 = 0.0f;
+            if (live) for (int t = 0; t < tiles; ++t) { const float* pp = pb + ((long)t * C + c) * 2; const float d = pp[0] - mean; m2 += pp[1] + 128.0f * d * d; }
+            for (int o = 1; o < cg; o <<= 1) m2 += __shfl_xor(m2, o);
+            const float rstd = 1.0f / sqrtf(m2 / (128.0f * (float)(tiles * cg)) + a.gn_eps);
+            if (c < a.Cin_pad) {
+                float2 st = make_float2(1.0f, 0.0f);
+                if (live) {
+                    const float ga = a.gn_gamma ? a.gn_gamma[c] : 1.0f, be = a.gn_beta ? a.gn_beta[c] : 0.0f;
+                    st = make_float2(rstd * ga, be - mean * rstd * ga);
+                }
+                *reinterpret_cast<float2*>(ssl + 2 * c) = st;
+            }
+        }
+    }
+    __syncthreads();                                       // (wmax is written again by the caller)
+}
+
 __device__ __forceinline__ void stage_ss_bound(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid, int nthr) {
+    if (a.gn_part) {                                       // folded GroupNorm: its output bound is a layer constant
+        stage_ss_from_partials(a, b, ssl, wmax, tid);
+        return;
+    }
     const bool has_ss = a.ss != nullptr;
     if (a.bound_final) {                                   // the bound is a launch constant: only stage the table
         for (int c = tid; c < a.Cin_pad; c += nthr) {
@@ -1168,7 +1228,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     const int BW = 1 << a.bw_log2, BH = TN >> a.bw_log2;
     const int HWin = a.Hin * a.Win;
     const float* xb = a.x + (long)b * a.x_bs;
-    const bool has_ss = a.ss != nullptr;
+    const bool has_ss = a.ss != nullptr || a.gn_part != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
     LNS_TS_DECL
     LNS_TSTAMP(0)
@@ -1517,7 +1577,7 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
     const int HW = a.Hin * a.Win;
     const int p0 = tx * TN;
     const float* xb = a.x + (long)b * a.x_bs;
-    const bool has_ss = a.ss != nullptr;
+    const bool has_ss = a.ss != nullptr || a.gn_part != nullptr;
     const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
     LNS_TS_DECL
     LNS_TSTAMP(0)
@@ -1760,7 +1820,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
     const int HW = a.Hin * a.Win;
     const int p0 = tx * TN;
     const float* xb = a.x + (long)b * a.x_bs;
-    const bool has_ss = a.ss != nullptr;
+    const bool has_ss = a.ss != nullptr || a.gn_part != nullptr;
     LNS_TS_DECL
     LNS_TSTAMP(0)
 

@@ -471,6 +471,8 @@ struct Planner {
                            pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok))
             throw std::runtime_error("no conv tiling for " + name);
         if (up2 && g.variant != CV_F64) throw std::runtime_error("phase form needs the f16x2 64-cout tiles: " + name);
+        if (in.act == ACT_GELU && (g.variant != CV_F64 || up2 || fuse_pack >= 0))
+            throw std::runtime_error("GELU prologue is only built into the f16x2 3x3 kernel: " + name);
         if (up2) { g.Hout = 2 * in.H; g.Wout = 2 * in.W; }
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
@@ -917,10 +919,21 @@ struct Planner {
         TRef h2 = conv_same3(h1, l.p_c3, l.dil, l.mode_y, l.mode_x, ACT_NONE, nullptr, tag(SP_WS, emb_off), q + ".conv1.3", false);
         free_t(h1);
         emit_gn(h2, 1, 1e-5f, l.c_g, l.c_b, 0, q + ".cond_conv1.0");
-        TRef h3 = emit_apply(h2, ACT_GELU, q + ".cond_conv1.1");
-        free_t(h2);
-        TRef x1 = conv_same3(h3, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2", false);
-        free_t(h3);
+        // GroupNorm -> GELU -> conv: the f16x2 3x3 kernel applies both in its prologue (mode 3); any other kernel gets the
+        // materialised tensor (round 2's form, LNS_NO_GELU_PROLOGUE=1)
+        static const bool no_gelu_pro = getenv("LNS_NO_GELU_PROLOGUE") != nullptr;
+        const ConvPack& cpk = e->packs[l.c_conv];
+        TRef x1;
+        if (!no_gelu_pro && cpk.has_wb && cpk.f16 && cpk.cout > 32) {
+            h2.act = ACT_GELU;
+            x1 = conv_same3(h2, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2", false);
+            free_t(h2);
+        } else {
+            TRef h3 = emit_apply(h2, ACT_GELU, q + ".cond_conv1.1");
+            free_t(h2);
+            x1 = conv_same3(h3, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2", false);
+            free_t(h3);
+        }
         TRef xin2 = x1; xin2.owned = false;
         emit_gn(xin2, 1, 1e-5f, l.p_g2, l.p_b2, tag(SP_WS, mul_off), q + ".ffn.0");
         TRef f1 = conv_same1(xin2, l.p_f1, ACT_GELU, nullptr, nullptr, q + ".ffn.1");

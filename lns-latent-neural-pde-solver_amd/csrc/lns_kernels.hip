@@ -420,6 +420,47 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
             if (KS == 1 && VEC) {
                 float4 t;
                 float* tp = &t.x;
+#if defined(LNS_PKEXP) && LNS_PKEXP >= 1
+                // Co-residency experiment (tools/pk_experiment.sh; built WITH packed-fp32 ops, never shipped): this is the
+                // victim's x * s + t whose SLP-vectorised form -- two v_pk_fma_f32 reading (s, t) through op_sel, the
+                // second one overwriting the (s, t) pair -- returned shift 0.0 for a quarter of a wave beside a 16-bit
+                // MFMA kernel.  1: four scalar v_fma_f32 (the vectoriser is fenced off); 2: the packed pair by hand, every
+                // destination a fresh register pair (early clobber: no aliasing with the op_sel source); 3: the packed
+                // pair by hand with the compiler's register assignment (second destination = the (s, t) pair).
+                typedef float pk2 __attribute__((ext_vector_type(2)));
+                float fv[4];
+                if (MODE >= 1) {
+#if LNS_PKEXP == 1
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float v = fmaf(pv[4 * q + u], st.x, st.y);
+                        asm volatile("" : "+v"(v));
+                        fv[u] = v;
+                    }
+#else
+                    pk2 sp = {st.x, st.y};
+                    const pk2 i0 = {pv[4 * q + 0], pv[4 * q + 1]}, i1 = {pv[4 * q + 2], pv[4 * q + 3]};
+                    pk2 o0, o1;
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=&v"(o0) : "v"(i0), "v"(sp));
+#if LNS_PKEXP == 2
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=&v"(o1) : "v"(i1), "v"(sp));
+#else
+                    asm volatile("v_pk_fma_f32 %0, %1, %0, %0 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "+v"(sp) : "v"(i1));
+                    o1 = sp;
+#endif
+                    fv[0] = o0[0]; fv[1] = o0[1]; fv[2] = o1[0]; fv[3] = o1[1];
+#endif
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fv[u] = pv[4 * q + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v = fv[u];
+                    if (MODE == 2) v = swish_fast(v);
+                    tp[u] = ok ? v : 0.0f;
+                }
+#else
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float v = pv[4 * q + u];
@@ -427,6 +468,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
                     if (MODE == 2) v = swish_fast(v);
                     tp[u] = ok ? v : 0.0f;
                 }
+#endif
                 *reinterpret_cast<float4*>(Xs + (tid + q * NTHR) * 4) = t;
             } else {
                 float v = pv[q];
@@ -1229,7 +1271,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     const int HWin = a.Hin * a.Win;
     const float* xb = a.x + (long)b * a.x_bs;
     const bool has_ss = a.ss != nullptr || a.gn_part != nullptr;
-    const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : 1) : 0;
+    // prologue: none / scale-shift / + Swish / + exact GELU (the conditional propagator's cond_conv1: GroupNorm -> GELU -> conv)
+    const int pro_mode = has_ss ? (a.act_in == ACT_SWISH ? 2 : (a.act_in == ACT_GELU ? 3 : 1)) : 0;
     LNS_TS_DECL
     LNS_TSTAMP(0)
 
@@ -1321,6 +1364,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             float v = pv[u][2 * cp + e];
             if (MODE >= 1) { const float2 st = *reinterpret_cast<const float2*>(ssl + 2 * (c0 + 2 * cp + e)); v = v * st.x + st.y; }
             if (MODE == 2) v = swish_fast(v);
+            if (MODE == 3) v = gelu_erfc(v);
             t[e] = v * uok[u];
         }
         if (SPL == 3) split3_pair(t[0], t[1], hq[u][cp], mq[u][cp], lq[u][cp]);
@@ -1334,6 +1378,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         float v0 = pv[u][2 * cp], v1 = pv[u][2 * cp + 1];
         if (MODE >= 1) { v0 = v0 * st.x + st.y; v1 = v1 * st.z + st.w; }
         if (MODE == 2) { v0 = swish_fast(v0); v1 = swish_fast(v1); }
+        if (MODE == 3) { v0 = gelu_erfc(v0); v1 = gelu_erfc(v1); }
         v0 *= uok[u]; v1 *= uok[u];
         if (SPL == 3) split3_pair(v0, v1, hq[u][cp], mq[u][cp], lq[u][cp]);
         else split2_pair_f16(v0, v1, hq[u][cp], mq[u][cp]);
@@ -1516,6 +1561,9 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         }
     };
     if (pro_mode == 2) k_loop(std::integral_constant<int, 2>{});
+    else if (pro_mode == 3) {                            // (f16x2 64 x 128 tiles only: the planner's rule)
+        if constexpr (SPL == 2 && NTAP == 9 && !FUSE2 && MT == 2 && NT == 1) k_loop(std::integral_constant<int, 3>{});
+    }
     else if (pro_mode == 1) k_loop(std::integral_constant<int, 1>{});
     else k_loop(std::integral_constant<int, 0>{});
 

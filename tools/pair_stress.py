@@ -29,6 +29,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         run("bf16x3 3x3 64->64  | fp32 1x1 64->64", 32, 64, 64, (64, 64, 3, 6), (64, 64, 1, -1), rounds=12)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "exp":       # the pairs that failed on round 2's packed-fp32 build, once each
+        run("bf16x3 1x1 64->64  | fp32 1x1 64->64", 32, 64, 64, (64, 64, 1, 7), (64, 64, 1, 1), rounds=12)
+        run("bf16x3 3x3 64->64  | fp32 1x1 64->512", 32, 64, 64, (64, 64, 3, 6), (64, 512, 1, -1), rounds=12)
+        run("bf16x3 3x3 64->64  | fp32 1x1 64->64 variant 4", 32, 64, 64, (64, 64, 3, 6), (64, 64, 1, 4))
+        run("bf16x3 3x3 128->128 16x16 | fp32 1x1 128->128", 64, 16, 16, (128, 128, 3, 6), (128, 128, 1, -1))
+        sys.exit(0)
     run("bf16x3 3x3 64->64  | fp32 1x1 64->64", 32, 64, 64, (64, 64, 3, 6), (64, 64, 1, -1))
     run("bf16x3 3x3 128->128 16x16 | fp32 1x1 128->128", 64, 16, 16, (128, 128, 3, 6), (128, 128, 1, -1))
     for v in (1, 3, 4):

@@ -687,6 +687,26 @@ def test_packed_fp32_corun():
     assert res["alone"]["packed_mismatches"] == 0, res        # single-stream runs never failed
 
 
+@pytest.mark.gpu
+def test_engine_pair_stress_is_clean_on_the_shipped_build():
+    """The regression test that actually guards the co-residency finding: the in-engine pair stress
+    (lns_op_conv_pair_stress: two convolutions on two streams, every output word compared with the kernel's solo
+    result) on the pairs that corrupt 1 024 .. 113 663 words as soon as the victim's x*s+t is a v_pk_fma_f32 with
+    op_sel broadcast (profiles/r03_pk_experiment.txt: with only that instruction pair made scalar the packed build
+    is clean; with the pair written by hand into non-aliasing registers it still fails).  Shipped build: 0 words."""
+    _need_gpu()
+    import ctypes
+    from lns_amd import _lib
+    L = _lib.lib()
+    L.lns_op_conv_pair_stress.restype = ctypes.c_int
+    L.lns_op_conv_pair_stress.argtypes = [ctypes.c_int] * 13 + [ctypes.POINTER(ctypes.c_longlong)] * 2
+    for name, B, H, W, a, b, rounds in (("f16 1x1 | fp32 1x1", 32, 64, 64, (64, 64, 1, 7), (64, 64, 1, 1), 6),
+                                        ("split 3x3 | fp32 1x1 64->512", 32, 64, 64, (64, 64, 3, 6), (64, 512, 1, -1), 4)):
+        ma, mb = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        rc = L.lns_op_conv_pair_stress(B, H, W, a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], rounds, 6, ctypes.byref(ma), ctypes.byref(mb))
+        assert rc == 0 and ma.value == 0 and mb.value == 0, (name, rc, ma.value, mb.value)
+
+
 # ---- SURVEY 8f-3: the latent TRAINING rollout, forward + backward through time on the HIP engine ---------------------
 GRAD_CASES = ["ns2d_mini", "twophase", "sw_half_periodic", "twophase_cond"]
 GRAD_TOL = 1e-4          # rel-L2 per parameter tensor against the REAL reference's loss.backward() (VERDICT r2, item 5)

@@ -525,6 +525,16 @@ struct Planner {
         if (k == 3) {
             a.rowmap = as_ptr<const int>(const_ints(rm));
             a.colmap = as_ptr<const int>(const_ints(cm));
+            // no resize, pads inside one period: the split-operand kernel computes the maps itself (ConvArgs::map_arith)
+            static const bool no_arith = getenv("LNS_NO_ARITH_MAPS") != nullptr;
+            const bool plain = up2 || (!in.vH && !in.vW);
+            if (!no_arith && plain && cv_is_split_3x3(g.variant) && pad[0] <= in.H && pad[1] <= in.H && pad[2] <= in.W && pad[3] <= in.W &&
+                (my == LNS_PAD_ZEROS || my == LNS_PAD_CIRCULAR) && (mx == LNS_PAD_ZEROS || mx == LNS_PAD_CIRCULAR)) {
+                a.map_arith = 1;
+                a.map_circ[0] = my == LNS_PAD_CIRCULAR; a.map_circ[1] = mx == LNS_PAD_CIRCULAR;
+                a.map_pad[0] = pad[0]; a.map_pad[1] = pad[2];
+                a.map_ext[0] = in.H + pad[0] + pad[1]; a.map_ext[1] = in.W + pad[2] + pad[3];
+            }
         }
         // 16-byte patch loads: every channel row of every sample must start 16-byte aligned
         a.vec4 = (k == 1 && ((in.H * in.W) % 4 == 0)) ? 1 : 0;
@@ -2088,6 +2098,14 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.w = oc.dw; a.bias = bias_host ? oc.dw + wcount : nullptr; a.ss = ss; a.act_in = act_in; a.act_out = act_out;
     if (wb_floats) a.wb = oc.dw + wcount + pk.Cout_pad;
     a.rowmap = oc.dmaps; a.colmap = oc.dmaps + rm.size();
+    if (ksize == 3 && Hv == Hin && Wv == Win && cv_is_split_3x3(g.variant) && getenv("LNS_NO_ARITH_MAPS") == nullptr &&
+        pad_t <= Hin && pad_b <= Hin && pad_l <= Win && pad_r <= Win && (mode_y == LNS_PAD_ZEROS || mode_y == LNS_PAD_CIRCULAR) &&
+        (mode_x == LNS_PAD_ZEROS || mode_x == LNS_PAD_CIRCULAR)) {       // same rule as Planner::emit_conv
+        a.map_arith = 1;
+        a.map_circ[0] = mode_y == LNS_PAD_CIRCULAR; a.map_circ[1] = mode_x == LNS_PAD_CIRCULAR;
+        a.map_pad[0] = pad_t; a.map_pad[1] = pad_l;
+        a.map_ext[0] = Hin + pad_t + pad_b; a.map_ext[1] = Win + pad_l + pad_r;
+    }
     a.vec4 = (ksize == 1 && ((Hin * Win) % 4 == 0)) ? 1 : 0;
     a.y = y; a.y_bs = (long)Cout * g.Hout * g.Wout; a.Cout = Cout; a.Hout = g.Hout; a.Wout = g.Wout;
     a.res = residual; a.res_bs = a.y_bs; a.badd = badd;

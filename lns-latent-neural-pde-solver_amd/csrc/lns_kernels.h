@@ -56,6 +56,11 @@ struct ConvArgs {
     // ([B][gn_tiles][Cin][2], ConvArgs::stat_part of that launch) plus gamma / beta; every block of a sample merges them
     // itself (same code, same order: same bits), which removes the statistics / finalize launch from the dependency chain
     const float* gn_part; const float* gn_gamma; const float* gn_beta; int gn_tiles, gn_groups; float gn_eps;
+    // split-operand 3x3 kernel: source maps computed in the kernel instead of read from rowmap / colmap (one memory latency
+    // less before a block's first patch loads).  Set by the planner when the layer has no resize and pads <= the plane:
+    // padded position p -> p - map_pad; outside [0, size): wrapped once (map_circ bit) or none; p >= map_ext: none.
+    // Index 0 = rows, 1 = columns.  The tables stay valid either way (every other kernel reads them).
+    int map_arith, map_circ[2], map_pad[2], map_ext[2];
     int ct_per_block;      // 1x1 bf16x3, input-stationary form: cout tiles walked by one block (0 = streaming form)
     // 3x3 split-operand kernel, 128-pixel tiles that cover the plane exactly: per (sample, pixel tile, channel)
     // (mean, centred second moment) of the stored output, [B][tiles][Cout][2]; the following GroupNorm merges them

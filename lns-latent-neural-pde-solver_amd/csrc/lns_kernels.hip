@@ -822,6 +822,8 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned& h, unsig
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // two fp32 values -> packed (h, l) fp16 pairs with x = h + l to ~23 bits (RNE: v_cvt_pk_f16_f32)
 __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, unsigned& l) {
@@ -1232,12 +1234,13 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int PH = a.PH, PW = a.PW;
     const int PLANE = PH * PW;
-    const int PP1 = PLANE + 1;                         // plane stride in units; unit PLANE = write sink
-    const int xb_bytes = SPL * PP1 * 16;
+    const int PP1 = PLANE + 1;                         // units per buffer; unit PLANE = write sink
+    constexpr int UB = SPL * 16;                       // a unit = one patch pixel: [split][8 ch] 16-bit, the splits side by side
+    const int xb_bytes = PP1 * UB;                     //  (immediate offsets between them; 32-byte lane stride: conflict-free reads)
     const int buf_bytes = xb_bytes + SLAB;
     char* lds = smem;                                                  // 2 x [Xb | Wb]
-    char* zunit = lds + 2 * buf_bytes;                              // one all-zero 16-byte unit
-    float* ssl = reinterpret_cast<float*>(zunit + 16);                 // [Cin_pad][2]
+    char* zunit = lds + 2 * buf_bytes;                              // one all-zero unit
+    float* ssl = reinterpret_cast<float*>(zunit + UB);                 // [Cin_pad][2]
     float* addv = ssl + a.Cin_pad * 2;                                 // [64] bias + per-sample add of this cout tile
     unsigned* wmax = reinterpret_cast<unsigned*>(addv + 64);           // [4] per-wave share of the activation bound
 
@@ -1280,7 +1283,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // maps of this thread's patch units (direct loads, no LDS round trip), the GroupNorm scale/shift table and the
     // epilogue's add vector (to LDS) -- so the block pays ONE memory latency before its first patch loads, and the
     // epilogue none.
-    int udm[NU], uslot[NU];
+    unsigned udm[NU];                 // byte offset of the unit's source pixel inside a channel plane (zero-extended lane
+    int uslot[NU];                    //  offset + uniform channel base = the scalar-base form of the global load)
     float uok[NU];
     {
         int sy[NU], sx[NU];
@@ -1289,19 +1293,28 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             const int p = tid + u * NTHR;
             const int pc = p < PLANE ? p : 0;
             const int py = pc / PW, px = pc - py * PW;
-            sy[u] = a.rowmap[ty * BH * a.stride + py];
-            sx[u] = a.colmap[tx * BW * a.stride + px];
+            const int qy = ty * BH * a.stride + py, qx = tx * BW * a.stride + px;
+            if (a.map_arith) {       // (uniform) the planner's build_axis_map() without resize, in registers
+                int uy = qy - a.map_pad[0], ux = qx - a.map_pad[1];
+                if (uy < 0) uy = a.map_circ[0] ? uy + a.Hin : -1; else if (uy >= a.Hin) uy = a.map_circ[0] ? uy - a.Hin : -1;
+                if (ux < 0) ux = a.map_circ[1] ? ux + a.Win : -1; else if (ux >= a.Win) ux = a.map_circ[1] ? ux - a.Win : -1;
+                sy[u] = qy < a.map_ext[0] ? uy : -1;
+                sx[u] = qx < a.map_ext[1] ? ux : -1;
+            } else {
+                sy[u] = a.rowmap[qy];
+                sx[u] = a.colmap[qx];
+            }
         }
-        if (tid < 4) reinterpret_cast<unsigned*>(zunit)[tid] = 0u;
+        if (tid < UB / 4) reinterpret_cast<unsigned*>(zunit)[tid] = 0u;
         // patch units: unit u = pixel (tid + u*256) of the patch; spatial source offset or none.
         // Threads past the end of the patch stage into the sink unit, so the K loop has no branches.
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int p = tid + u * NTHR;
             const bool ok = p < PLANE && sy[u] >= 0 && sx[u] >= 0;
-            udm[u] = ok ? sy[u] * a.Win + sx[u] : 0;
+            udm[u] = ok ? (unsigned)(sy[u] * a.Win + sx[u]) * 4u : 0u;
             uok[u] = ok ? 1.0f : 0.0f;                          // times the activation scale once the bound is known
-            uslot[u] = (p < PLANE ? p : PLANE) * 16;
+            uslot[u] = (p < PLANE ? p : PLANE) * UB;
         }
     }
     // (the scale/shift table, the add vector and the activation bound are staged inside k_loop, BEHIND the first
@@ -1313,6 +1326,12 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)(ct * MT / 2) * (a.Cin_pad / KC) * wstage +
                         (UP2 ? (long)phase * SLAB64 : 0) + (MT == 1 ? (ct & 1) * 512 : 0);
 
+    // Both operand streams are read through buffer descriptors: lane offset in ONE VGPR, the stage's channel / slab offset
+    // in an SGPR -- no 64-bit vector address arithmetic in the K loop (the flat form cost a v_lshl_add_u64 per load).
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.Cin * HWin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wslab), 0,
+                                                                        (int)((a.Cin_pad / KC) * wstage), 0x00020000);
+
     // per-lane operand offsets (bytes).  K of one MFMA = 2 taps x 8 channels: lane half kh takes tap 2j+kh.
     // The 10th tap does not exist: in k-step 4 the kh=1 lanes multiply the shared zero unit with tap 8's
     // (finite) weights.
@@ -1320,13 +1339,13 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
-        boff[nt] = (((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride) * 16;
+        boff[nt] = (((p >> a.bw_log2) * a.stride) * PW + (p & (BW - 1)) * a.stride) * UB;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int t = 2 * j + kh;
         const int tc = t < NTAP ? t : NTAP - 1;
-        ltoff[j] = UP2 ? (((tc >> 1) + pa) * PW + (tc & 1) + pb) * 16 : (((tc / 3) * a.dil) * PW + (tc % 3) * a.dil) * 16;
+        ltoff[j] = UP2 ? (((tc >> 1) + pa) * PW + (tc & 1) + pb) * UB : (((tc / 3) * a.dil) * PW + (tc % 3) * a.dil) * UB;
         aoff[j] = (tc * TM + l31) * 16;
     }
     const bool ztap = kh != 0;                          // nine taps: in k-step 4 this lane half reads the zero unit
@@ -1345,14 +1364,14 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 
     // channel pair cp (channels 2cp, 2cp+1 of a stage) of unit u: global -> registers.
     // Straight-line code (no per-element branches, so the scheduler can interleave it with MFMAs):
-    // a padded pixel reads pixel 0 and is multiplied by 0 later; a channel past Cin reads channel 0
+    // a padded pixel reads pixel 0 and is multiplied by 0 later; a channel past Cin reads the last channel
     // (finite data) and meets zero weights.
+    const int cin_m1 = a.Cin - 1, hw4 = HWin * 4;
     auto load_pair = [&](int u, int cp, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int c = c0 + 2 * cp + e;
-            const float* cb = xb + (long)(c < a.Cin ? c : 0) * HWin;     // uniform
-            pv[u][2 * cp + e] = cb[udm[u]];
+            pv[u][2 * cp + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)udm[u], min(c, cin_m1) * hw4, 0));
         }
     };
     // prologue transform + 3-way split of one channel pair
@@ -1386,15 +1405,15 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     auto flush_unit = [&](int u, char* Xn) __attribute__((always_inline)) {
         char* dst = Xn + uslot[u];
         *reinterpret_cast<uint4*>(dst) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
-        *reinterpret_cast<uint4*>(dst + PP1 * 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
-        if (SPL == 3) *reinterpret_cast<uint4*>(dst + 2 * PP1 * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
+        *reinterpret_cast<uint4*>(dst + 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
+        if (SPL == 3) *reinterpret_cast<uint4*>(dst + 32) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
     };
     auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
         const int idx = tid + i * NTHR;                  // 16-byte unit inside the slab
         const int off = idx < SLAB / 16 ? idx : SLAB / 16 - 1;
-        const int src = MT == 1 ? (off >> 5) * 1024 + (off & 31) * 16 : off * 16;     // row of 64 couts -> its 32
-        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * wstage + src);
-        wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
+        const unsigned src = MT == 1 ? (off >> 5) * 1024 + (off & 31) * 16 : off * 16;     // row of 64 couts -> its 32
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)src, (c0 >> 3) * (int)wstage, 0);
+        wq[i][0] = __uint_as_float(t[0]); wq[i][1] = __uint_as_float(t[1]); wq[i][2] = __uint_as_float(t[2]); wq[i][3] = __uint_as_float(t[3]);
     };
     auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
         const int idx = tid + i * NTHR;                  // the last slot's tail rewrites the slab's last unit
@@ -1412,9 +1431,9 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                 af[s][mt] = *reinterpret_cast<const uint4*>(Ws + s * (NTAP * TM * 16) + mt * (32 * 16) + aoff[j]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const char* p = Xs + s * PP1 * 16 + boff[nt] + ltoff[j];
+                const char* p = Xs + boff[nt] + ltoff[j];
                 if (j == NJ - 1 && (NTAP & 1)) p = ztap ? zunit : p;
-                bf[s][nt] = *reinterpret_cast<const uint4*>(p);
+                bf[s][nt] = *reinterpret_cast<const uint4*>(p + s * 16);
             }
         }
     };
@@ -1635,18 +1654,24 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
 
     // two staging units (pixel, octet) per thread.  VEC2 (even H*W): two adjacent pixels of one octet, fetched
     // with 8-byte loads; otherwise one pixel, octets o and o + 2.
+    // (the octet is wave-uniform: kept in an SGPR, so a load's channel offset is scalar arithmetic and the loads take
+    //  the buffer form -- lane offset in one VGPR, channel offset in an SGPR, no 64-bit vector address arithmetic)
     int upx[NU], uoct[NU], udm[NU];
     float uok[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         upx[u] = VEC2 ? 2 * (tid & 63) + u : (tid & 127);
-        uoct[u] = VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u;
+        uoct[u] = __builtin_amdgcn_readfirstlane(VEC2 ? (tid >> 6) : (tid >> 7) + 2 * u);
         const bool pvalid = p0 + upx[u] < HW;
-        udm[u] = pvalid ? p0 + upx[u] : 0;
+        udm[u] = pvalid ? (p0 + upx[u]) * 4 : 0;           // byte offset inside a channel plane
         uok[u] = pvalid ? 1.0f : 0.0f;                     // times the activation scale once the bound is known
     }
     float xinv = 1.0f;
     const char* wslab = reinterpret_cast<const char*>(a.wb) + (long)ct * (a.Cin_pad / KC) * CONVB1_SLAB_BYTES;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.Cin * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wslab), 0,
+                                                                        (a.Cin_pad / KC) * CONVB1_SLAB_BYTES, 0x00020000);
+    const int cin_m1 = a.Cin - 1, hw4 = HW * 4;
     const int aoff = (kh * TM + l31) * 16;                 // + (s*4 + 2j) * TM*16 + mt*32*16
     const int boff = (kh * TN + wn * 32 + l31) * 16;       // + (s*4 + 2j) * TN*16
 
@@ -1664,17 +1689,19 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
     auto load_pairs = [&](int cp, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
+            // (a channel past Cin reads the last channel: finite data that meets zero weights)
             if (VEC2) {
                 const int c = c0 + uoct[0] * 8 + 2 * cp + e;           // uniform per wave
-                const float* cb = xb + (long)(c < a.Cin ? c : 0) * HW;
-                const float2 t = *reinterpret_cast<const float2*>(cb + udm[0]);
+                // (flat 8-byte loads: the buffer form of this streaming read measured 7 % slower on the HBM-bound
+                //  64 -> 64 layer at 128^2, 122 vs 114 us, although it needs one vector instruction less per load)
+                const char* cb = reinterpret_cast<const char*>(xb) + (long)min(c, cin_m1) * hw4;     // scalar
+                const float2 t = *reinterpret_cast<const float2*>(cb + (unsigned)udm[0]);
                 pv[0][2 * cp + e] = t.x; pv[1][2 * cp + e] = t.y;
             } else {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int c = c0 + uoct[u] * 8 + 2 * cp + e;
-                    const float* cb = xb + (long)(c < a.Cin ? c : 0) * HW;
-                    pv[u][2 * cp + e] = cb[udm[u]];
+                    pv[u][2 * cp + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, udm[u], min(c, cin_m1) * hw4, 0));
                 }
             }
         }
@@ -1702,11 +1729,11 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
         if (SPL == 3) *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
     };
     auto load_w = [&](int i, int c0) __attribute__((always_inline)) {
-        const float4 t = *reinterpret_cast<const float4*>(wslab + (long)(c0 / KC) * CONVB1_SLAB_BYTES + (long)(tid + i * NTHR) * 16);
-        wq[i][0] = t.x; wq[i][1] = t.y; wq[i][2] = t.z; wq[i][3] = t.w;
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wr, (tid + i * NTHR) * 16, (c0 >> 5) * CONVB1_SLAB_BYTES, 0);
+        wq[i][0] = __uint_as_float(t[0]); wq[i][1] = __uint_as_float(t[1]); wq[i][2] = __uint_as_float(t[2]); wq[i][3] = __uint_as_float(t[3]);
     };
     auto write_w = [&](int i, char* Wn) __attribute__((always_inline)) {
-        *reinterpret_cast<float4*>(Wn + (long)(tid + i * NTHR) * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
+        *reinterpret_cast<float4*>(Wn + (tid + i * NTHR) * 16) = make_float4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
     };
     auto load_frags = [&](int j, const char* Xs, const char* Ws, uint4 (&af)[SPL][MT], uint4 (&bf)[SPL])
                           __attribute__((always_inline)) {
@@ -2085,7 +2112,7 @@ size_t convb_lds_bytes(const ConvArgs& a, int tm, int spl, int ring) {
     const size_t slab = a.up2 ? (size_t)spl * 4 * 64 * 16 : (size_t)CONVB_SLAB_BYTES * spl / 3 * tm / 64;
     // the epilogue reuses the stage buffers: GroupNorm tile statistics need 64 x 133 floats, the fused 1x1 conv its weights
     const size_t stage = std::max(ring * (spl * pp1 * 16 + slab), (size_t)64 * 133 * 4 + 64);
-    return stage + 16 + ((size_t)a.Cin_pad * 2 + 64) * 4 + 16 + 16;
+    return stage + spl * 16 + ((size_t)a.Cin_pad * 2 + 64) * 4 + 16 + 16;
 }
 
 bool convb_fits(const ConvArgs& a) {

@@ -302,6 +302,9 @@ struct Planner {
         static const bool off = getenv("LNS_GN_NO_FUSE") != nullptr;
         if (off) return;
         stat_cap = (size_t)B * 128 * e->cfg.Ly * e->cfg.Lx / GN_TILE_PIXELS * 8;   // C * H * W <= 128 * Ly * Lx
+        // (a propagator-only engine has no field size: room for what the latent chain folds, <= 4 tiles x 512 channels,
+        //  so that it takes the same per-layer decisions -- the same bits -- as the propagator inside a full model)
+        stat_cap = std::max(stat_cap, (size_t)B * 4 * 512 * 8);
         for (int i = 0; i < STAT_RING; ++i) stat_ring[i] = tag(SP_WS, arena.alloc(stat_cap));
         stat_scratch = stat_ring[0];
     }
@@ -404,18 +407,28 @@ struct Planner {
         static const long min_hw = getenv("LNS_GN_FUSE_MIN_HW") ? atol(getenv("LNS_GN_FUSE_MIN_HW")) : (no_fold ? 1024 : 256);
         Op* prod = nullptr;
         for (size_t i = plan->ops.size(); i-- > 0;) {
-            if (plan->ops[i].type == OP_TRACE) continue;
+            // (traces and the conditional blocks' per-sample vector ops touch no activation tensor)
+            const int ty = plan->ops[i].type;
+            if (ty == OP_TRACE || ty == OP_CONDBLK || ty == OP_CONDBASE || ty == OP_VECLIN) continue;
             prod = &plan->ops[i];
             break;
         }
         // producers with the statistics epilogue: the split-operand 3x3 kernels and the streaming 1x1 kernel (not its
         // input-stationary form, not with a fused second conv: its statistics would be taken of the wrong tensor... they
         // are taken of what is stored, which is right -- but only the plain form is covered by tests)
+        // Planes below 128 pixels (the 7 x 15 latents of the two-phase models) are ONE ragged tile: its epilogue takes exact
+        // two-pass statistics over the valid pixels (ConvArgs::stat_count) -- the three statistics launches per conditional
+        // block were a quarter of config 4's dependency chain.  A per-sample channel multiplier (premul) is applied
+        // to the partials by whoever merges them.
+        static const bool no_ragged = getenv("LNS_GN_NO_RAGGED") != nullptr;
+        const bool ragged1 = !no_fold && !no_ragged && prod && prod->type == OP_CONV && !prod->conv.up2 &&
+                             prod->conv.tiles_x * prod->conv.tiles_y == 1 && x.H * x.W < GN_TILE_PIXELS;
         const bool prod_ok = prod && prod->type == OP_CONV &&
                              (prod->variant == CV_F64 || prod->variant == CV_B64 ||
-                              (prod->variant == CV_B1 && !no_fold && prod->conv.ct_per_block == 0 && !prod->conv.w2 && (x.H * x.W) % GN_TILE_PIXELS == 0));
-        if (stat_scratch && !premul && prod_ok &&
-            prod->conv.y == as_ptr<float>(x.ptr) && prod->conv.Cout == x.C && (long)x.H * x.W >= min_hw) {
+                              (prod->variant == CV_B1 && !no_fold && prod->conv.ct_per_block == 0 && !prod->conv.w2 &&
+                               ((x.H * x.W) % GN_TILE_PIXELS == 0 || ragged1)));
+        if (stat_scratch && (!premul || ragged1) && prod_ok &&
+            prod->conv.y == as_ptr<float>(x.ptr) && prod->conv.Cout == x.C && ((long)x.H * x.W >= min_hw || ragged1)) {
             const ConvArgs& c = prod->conv;
             const int BW = 1 << c.bw_log2, BH = GN_TILE_PIXELS / BW;
             // (phase form of an upsampling conv: tiles are SOURCE tiles, each computed for four output phases)
@@ -424,7 +437,7 @@ struct Planner {
             // the 128-pixel tiles cover the plane exactly (1x1: tiles of 128 consecutive pixels)
             const bool exact = c.ks == 1 ? (c.tiles_x * GN_TILE_PIXELS == x.H * x.W && c.tiles_y == 1)
                                          : (c.tiles_x * BW * um == x.W && c.tiles_y * BH * um == x.H);
-            if (exact && (size_t)B * tiles * x.C * 8 <= stat_cap) {
+            if ((exact || ragged1) && (size_t)B * tiles * x.C * 8 <= stat_cap) {
                 // foldable into the consumer's prologue: few tiles, one group or power-of-two groups within a wave
                 const int cg = x.C / groups;
                 static const int fold_tiles = getenv("LNS_GN_FOLD_TILES") ? atoi(getenv("LNS_GN_FOLD_TILES")) : 2;
@@ -435,6 +448,8 @@ struct Planner {
                 prod->conv.stat_part = as_ptr<float>(region);
                 op.gn_tile_part = as_ptr<const float>(region);
                 op.gn_tiles = tiles;
+                op.gn_count = ragged1 ? x.H * x.W : GN_TILE_PIXELS;
+                if (ragged1) prod->conv.stat_count = x.H * x.W;
                 op.bytes = 2.0 * B * tiles * x.C * 8;
                 lazy_ops.push_back(op);
                 if (foldable) { x.gn_lazy = li; return; }
@@ -515,6 +530,7 @@ struct Planner {
                 const Op& lo = lazy_ops[in.gn_lazy];
                 a.ss = nullptr;
                 a.gn_part = lo.gn_tile_part; a.gn_tiles = lo.gn_tiles; a.gn_groups = lo.gn.groups; a.gn_eps = lo.gn.eps;
+                a.gn_count = lo.gn_count == GN_TILE_PIXELS ? 0 : lo.gn_count; a.gn_premul = lo.gn.premul;
                 a.gn_gamma = lo.gn.gamma; a.gn_beta = lo.gn.beta;
                 lazy_folded[in.gn_lazy] = 1;
             } else {
@@ -1301,7 +1317,7 @@ struct Runner {
                     ConvArgs a = op.conv;
                     fix(a.x, B); fix(a.w, B); fix(a.bias, B); fix(a.ss, B); fix(a.rowmap, B); fix(a.colmap, B);
                     fix(a.y, B); fix(a.res, B); fix(a.badd, B); fix(a.w2, B); fix(a.bias2, B); fix(a.wb, B); fix(a.stat_part, B);
-                    fix(a.amax_in, B); fix(a.amax_out, B); fix(a.gn_part, B); fix(a.gn_gamma, B); fix(a.gn_beta, B);
+                    fix(a.amax_in, B); fix(a.amax_out, B); fix(a.gn_part, B); fix(a.gn_gamma, B); fix(a.gn_beta, B); fix(a.gn_premul, B);
                     if (a.y_bs < 0) {          // output handed in by the caller: may be addressed in two levels (step-batched decode)
                         const int sl = SP_EXT0 + (int)(-a.y_bs - 1);
                         a.y_bs2 = B.bs2[sl]; a.y_bdiv = B.bdiv[sl];
@@ -1309,7 +1325,7 @@ struct Runner {
                     if (a.x_bs < 0 && B.bdiv[SP_EXT0 + (int)(-a.x_bs - 1)]) B.bad = true;   // inputs are always plain
                     fixbs(a.x_bs, B); fixbs(a.y_bs, B); fixbs(a.res_bs, B);
                     if (!all_untagged(a.x, a.w, a.bias, a.ss, a.rowmap, a.colmap, a.y, a.res, a.badd, a.w2, a.bias2, a.wb, a.stat_part,
-                                      a.amax_in, a.amax_out, a.gn_part, a.gn_gamma, a.gn_beta)) B.bad = true;
+                                      a.amax_in, a.amax_out, a.gn_part, a.gn_gamma, a.gn_beta, a.gn_premul)) B.bad = true;
                     if (B.bad) break;
 #ifdef LNS_TS
                     // diagnostic build: per-block phase timestamps of the layer named by $LNS_TS_LAYER, appended to $LNS_TS_FILE
@@ -1348,7 +1364,7 @@ struct Runner {
                     if (op.gn_tiles) {
                         const float* tp = op.gn_tile_part;
                         fix(tp, B);
-                        rc = launch_gn_tile_finalize(a, tp, op.gn_tiles, stream);
+                        rc = launch_gn_tile_finalize(a, tp, op.gn_tiles, op.gn_count ? op.gn_count : GN_TILE_PIXELS, stream);
                         break;
                     }
                     rc = launch_gn_stats(a, a.ss + (size_t)a.B * a.C * 2, stream);

@@ -56,6 +56,10 @@ struct ConvArgs {
     // ([B][gn_tiles][Cin][2], ConvArgs::stat_part of that launch) plus gamma / beta; every block of a sample merges them
     // itself (same code, same order: same bits), which removes the statistics / finalize launch from the dependency chain
     const float* gn_part; const float* gn_gamma; const float* gn_beta; int gn_tiles, gn_groups; float gn_eps;
+    // ragged single tile (planes below 128 pixels, e.g. the 7 x 15 latents of the two-phase models): the producer's
+    // partial covers stat_count valid pixels (0 = the full 128), the consumer divides by gn_count (0 = 128);
+    // gn_premul [B][Cin] or null: statistics of x * premul, the GroupNorm's per-sample channel multiplier
+    int stat_count, gn_count; const float* gn_premul;
     // split-operand 3x3 kernel: source maps computed in the kernel instead of read from rowmap / colmap (one memory latency
     // less before a block's first patch loads).  Set by the planner when the layer has no resize and pads <= the plane:
     // padded position p -> p - map_pad; outside [0, size): wrapped once (map_circ bit) or none; p >= map_ext: none.
@@ -156,7 +160,7 @@ bool gn_stats_two_stage(const GnStatsArgs& a);
 hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s);
 // GroupNorm scale/shift from the per-tile partials a convolution epilogue left (ConvArgs::stat_part); a.x unused
 #define GN_TILE_PIXELS 128
-hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, hipStream_t s);
+hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, int count, hipStream_t s);
 
 // LayerNorm over channels of a channel-major token tensor + positional embedding
 struct LnPeArgs {

@@ -150,14 +150,34 @@ __device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b,
     const int C = a.Cin, tiles = a.gn_tiles;
     const float* pb = a.gn_part + (long)b * tiles * C * 2;
     float* red = reinterpret_cast<float*>(wmax);
-    if (a.gn_groups == 1) {
+    const float cnt = a.gn_count ? (float)a.gn_count : 128.0f;     // pixels behind every partial
+    if (a.gn_groups == 1 && a.gn_premul) {
+        // statistics of x * p (per-sample channel multiplier): mean_c -> p mean_c, M2_c -> p^2 M2_c, scale -> scale * p
+        const float* pm = a.gn_premul + (long)b * C;
+        const int E = tiles * C;
+        float sm = 0.0f;
+        for (int i = tid; i < E; i += 256) sm += pm[i % C] * pb[2 * i];
+        const float mean = block_sum_256(sm, red) / (float)E;
+        float m2 = 0.0f;
+        for (int i = tid; i < E; i += 256) { const float p = pm[i % C], d = p * pb[2 * i] - mean; m2 += p * p * pb[2 * i + 1] + cnt * d * d; }
+        const float var = block_sum_256(m2, red) / (cnt * (float)E);
+        const float rstd = 1.0f / sqrtf(var + a.gn_eps);
+        for (int c = tid; c < a.Cin_pad; c += 256) {
+            float2 st = make_float2(1.0f, 0.0f);
+            if (c < C) {
+                const float ga = a.gn_gamma ? a.gn_gamma[c] : 1.0f, be = a.gn_beta ? a.gn_beta[c] : 0.0f;
+                st = make_float2(rstd * ga * pm[c], be - mean * rstd * ga);
+            }
+            *reinterpret_cast<float2*>(ssl + 2 * c) = st;
+        }
+    } else if (a.gn_groups == 1) {
         const int E = tiles * C;
         float sm = 0.0f;
         for (int i = tid; i < E; i += 256) sm += pb[2 * i];
         const float mean = block_sum_256(sm, red) / (float)E;
         float m2 = 0.0f;
-        for (int i = tid; i < E; i += 256) { const float d = pb[2 * i] - mean; m2 += pb[2 * i + 1] + 128.0f * d * d; }
-        const float var = block_sum_256(m2, red) / (128.0f * (float)E);
+        for (int i = tid; i < E; i += 256) { const float d = pb[2 * i] - mean; m2 += pb[2 * i + 1] + cnt * d * d; }
+        const float var = block_sum_256(m2, red) / (cnt * (float)E);
         const float rstd = 1.0f / sqrtf(var + a.gn_eps);
         for (int c = tid; c < a.Cin_pad; c += 256) {
             float2 st = make_float2(1.0f, 0.0f);
@@ -177,9 +197,9 @@ __device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b,
             for (int o = 1; o < cg; o <<= 1) sm += __shfl_xor(sm, o);
             const float mean = sm / (float)(tiles * cg);
             float m2 = 0.0f;
-            if (live) for (int t = 0; t < tiles; ++t) { const float* pp = pb + ((long)t * C + c) * 2; const float d = pp[0] - mean; m2 += pp[1] + 128.0f * d * d; }
+            if (live) for (int t = 0; t < tiles; ++t) { const float* pp = pb + ((long)t * C + c) * 2; const float d = pp[0] - mean; m2 += pp[1] + cnt * d * d; }
             for (int o = 1; o < cg; o <<= 1) m2 += __shfl_xor(m2, o);
-            const float rstd = 1.0f / sqrtf(m2 / (128.0f * (float)(tiles * cg)) + a.gn_eps);
+            const float rstd = 1.0f / sqrtf(m2 / (cnt * (float)(tiles * cg)) + a.gn_eps);
             if (c < a.Cin_pad) {
                 float2 st = make_float2(1.0f, 0.0f);
                 if (live) {
@@ -1147,6 +1167,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     const float v = acc[mt][nt][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)vr, 0, 0);
                     am = max(am, vr < nb ? abs_bits(v) : 0u);
+                    if (stats) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
                 }
         }
     } else
@@ -1173,23 +1194,53 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     }
     LNS_ETS(4)
     if (stats) {
+        // ragged single tile (ConvArgs::stat_count valid pixels): which of a wave's 32 pixels exist, one word per wave
+        unsigned* smask = reinterpret_cast<unsigned*>(sb + 64 * SROW);
+        const unsigned long long have = __builtin_amdgcn_ballot_w64(pix[0] >= 0);     // (all lanes: lanes 0..31 are the wave's pixels)
+        if (a.stat_count && (tid & 63) == 0) smask[tid >> 6] = (unsigned)have;
         __syncthreads();
         const int c = tid >> 2, q = tid & 3;
         const float* row = sb + c * SROW + q * 33;
         float v[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) v[i] = row[i];
+        float mean, m2;
+        if (a.stat_count) {
+            // exact two-pass statistics over the valid pixels: the four threads of a channel add their masked sums (quad
+            // permutes; every lane gets the same total), then their masked squared deviations from the common mean
+            const unsigned mk = smask[q];
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; i += 4) {
+                s0 += (mk >> i) & 1u ? v[i] : 0.0f; s1 += (mk >> (i + 1)) & 1u ? v[i + 1] : 0.0f;
+                s2 += (mk >> (i + 2)) & 1u ? v[i + 2] : 0.0f; s3 += (mk >> (i + 3)) & 1u ? v[i + 3] : 0.0f;
+            }
+            float sm = (s0 + s1) + (s2 + s3);
+            sm += dpp_quad<0xB1>(sm);
+            sm += dpp_quad<0x4E>(sm);
+            mean = sm / (float)a.stat_count;
+            float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; i += 4) {
+                const float d0 = v[i] - mean, d1 = v[i + 1] - mean, d2 = v[i + 2] - mean, d3 = v[i + 3] - mean;
+                q0 += (mk >> i) & 1u ? d0 * d0 : 0.0f; q1 += (mk >> (i + 1)) & 1u ? d1 * d1 : 0.0f;
+                q2 += (mk >> (i + 2)) & 1u ? d2 * d2 : 0.0f; q3 += (mk >> (i + 3)) & 1u ? d3 * d3 : 0.0f;
+            }
+            m2 = (q0 + q1) + (q2 + q3);
+            m2 += dpp_quad<0xB1>(m2);
+            m2 += dpp_quad<0x4E>(m2);
+        } else {
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 32; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
-        float mean = ((s0 + s1) + (s2 + s3)) * (1.0f / 32.0f);
+        mean = ((s0 + s1) + (s2 + s3)) * (1.0f / 32.0f);
         float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 32; i += 4) {
             const float d0 = v[i] - mean, d1 = v[i + 1] - mean, d2 = v[i + 2] - mean, d3 = v[i + 3] - mean;
             q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
         }
-        float m2 = (q0 + q1) + (q2 + q3);
+        m2 = (q0 + q1) + (q2 + q3);
         {   // 32 + 32 pixels, then 64 + 64 (lanes of one quad: DPP quad_perm, no LDS round trip)
             const float mo = dpp_quad<0xB1>(mean), qo = dpp_quad<0xB1>(m2), d = mean - mo;      // [1,0,3,2]
             m2 = (m2 + qo) + d * d * 16.0f;
@@ -1199,6 +1250,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             const float mo = dpp_quad<0x4E>(mean), qo = dpp_quad<0x4E>(m2), d = mean - mo;      // [2,3,0,1]
             m2 = (m2 + qo) + d * d * 32.0f;
             mean = 0.5f * (mean + mo);
+        }
         }
         const int co = ct * TM + c;
         if (q == 0 && co < a.Cout) {
@@ -2653,38 +2705,42 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnStatsArgs a, const fl
 
 // GroupNorm scale/shift from the per-tile (mean, M2) partials a convolution epilogue left: [B][tiles][C][2], every
 // partial over GN_TILE_PIXELS values.  One block per (group, sample); fixed order, exact merge of equal-count sets.
-__global__ __launch_bounds__(256) void gn_tile_finalize_kernel(GnStatsArgs a, const float* part, int tiles) {
+// `count` pixels behind every partial (GN_TILE_PIXELS, or the plane of a ragged single tile); a.premul as in gn_stats_kernel.
+__global__ __launch_bounds__(256) void gn_tile_finalize_kernel(GnStatsArgs a, const float* part, int tiles, int count) {
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y;
     const int cg = a.C / a.groups;
     const int E = tiles * cg;
     const float* pb = part + (long)b * tiles * a.C * 2;
+    const float* pm = a.premul ? a.premul + (long)b * a.C + g * cg : nullptr;
+    const float cnt = (float)count;
     float sm = 0.0f;
     for (int i = threadIdx.x; i < E; i += 256) {
         const int t = i / cg, c = i - t * cg;
-        sm += pb[((long)t * a.C + g * cg + c) * 2];
+        const float mc = pb[((long)t * a.C + g * cg + c) * 2];
+        sm += pm ? pm[c] * mc : mc;
     }
     const float mean = block_sum_256(sm, red) / (float)E;
     float m2 = 0.0f;
     for (int i = threadIdx.x; i < E; i += 256) {
         const int t = i / cg, c = i - t * cg;
         const float* pp = pb + ((long)t * a.C + g * cg + c) * 2;
-        const float d = pp[0] - mean;
-        m2 += pp[1] + (float)GN_TILE_PIXELS * d * d;
+        if (pm) { const float p = pm[c], d = p * pp[0] - mean; m2 += p * p * pp[1] + cnt * d * d; }
+        else { const float d = pp[0] - mean; m2 += pp[1] + cnt * d * d; }
     }
-    const float var = block_sum_256(m2, red) / ((float)GN_TILE_PIXELS * (float)E);
+    const float var = block_sum_256(m2, red) / (cnt * (float)E);
     const float rstd = 1.0f / sqrtf(var + a.eps);
     for (int c = threadIdx.x; c < cg; c += 256) {
         const int ch = g * cg + c;
         const float ga = a.gamma ? a.gamma[ch] : 1.0f;
         const float be = a.beta ? a.beta[ch] : 0.0f;
-        a.ss[((long)b * a.C + ch) * 2] = rstd * ga;
+        a.ss[((long)b * a.C + ch) * 2] = pm ? rstd * ga * pm[c] : rstd * ga;
         a.ss[((long)b * a.C + ch) * 2 + 1] = be - mean * rstd * ga;
     }
 }
 
-hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, hipStream_t s) {
-    hipLaunchKernelGGL(gn_tile_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a, tile_part, tiles);
+hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, int count, hipStream_t s) {
+    hipLaunchKernelGGL(gn_tile_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a, tile_part, tiles, count);
     return hipGetLastError();
 }
 

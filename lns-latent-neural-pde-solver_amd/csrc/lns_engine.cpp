@@ -572,6 +572,14 @@ struct Planner {
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles; a.bw_log2 = g.bw_log2;
         a.PH = g.PH; a.PW = g.PW; a.B = B;
         a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
+        if (up2) {
+            // narrow inputs: the split patch of ALL channels can stay in LDS while one block walks the four phases (same
+            // bits, conv3_up2r.inc).  Measured SLOWER (fused 128^2 layer 294 - 299 vs 215 us, rollout 31.9k vs 33.4k): at
+            // 147 KB of LDS a CU holds one block, and nothing overlaps its prologue, four epilogues and weight copies.
+            // Kept as an opt-in variant (LNS_UP2_RESIDENT=1) with its parity tests.
+            static const bool res = getenv("LNS_UP2_RESIDENT") != nullptr;
+            if (res) { a.up2 = 2; if (!convur_fits(a)) a.up2 = 1; }
+        }
         op.flops = 2.0 * B * g.Hout * g.Wout * (double)pk.cout * pk.cin * k * k;
         op.bytes = 4.0 * B * ((double)in.C * in.H * in.W + (double)pk.cout * g.Hout * g.Wout * (res ? 2 : 1));
         if (fuse_pack >= 0) {
@@ -2056,7 +2064,8 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     OPCHK(init_kernels());
     const bool stationary = tile_variant == 8;      // test code: 1x1 bf16x3 kernel in its input-stationary form
     if (stationary) tile_variant = CV_B1;
-    const bool up2 = tile_variant == 17;            // test code: f16x2 3x3 kernel, phase form of an exactly-2x nearest upsample
+    const bool up2r = tile_variant == 18;           // test code: ... its resident-patch form (conv3_up2r.inc)
+    const bool up2 = tile_variant == 17 || up2r;    // test code: f16x2 3x3 kernel, phase form of an exactly-2x nearest upsample
     if (up2) {
         if (ksize != 3 || stride != 1 || dilation != 1 || Hv != 2 * Hin || Wv != 2 * Win || pad_t != 1 || pad_b != 1 || pad_l != 1 || pad_r != 1) return LNS_EINVAL;
         tile_variant = CV_F64; Hv = Hin; Wv = Win;
@@ -2138,6 +2147,10 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     a.kc_log2 = g.sel_kc_log2; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.cout_tiles = g.cout_tiles;
     a.bw_log2 = g.bw_log2; a.PH = g.PH; a.PW = g.PW; a.B = B;
     a.ph_magic = g.PH > 1 ? (unsigned)((0x100000000ull + g.PH - 1) / g.PH) : 0u;
+    if (up2r) {
+        a.up2 = 2;
+        if (!convur_fits(a)) return LNS_EINVAL;
+    }
     if (stationary) {
         if (pk.Cin_pad > 64) return LNS_EINVAL;
         a.ct_per_block = g.cout_tiles < 3 ? g.cout_tiles : 3;

@@ -2351,6 +2351,7 @@ void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, i
     }
 }
 
+hipError_t launch_conv_up2r(const ConvArgs& a, hipStream_t s);
 hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     if (!convb_fits(a)) return hipErrorInvalidValue;
     if (cv_is_f16x2_3x3(variant) && !has_act_bound(a)) return hipErrorInvalidValue;
@@ -2363,6 +2364,7 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<2, 2, false, 2, 2>), grid, dim3(256), lds, s, a);
         return hipGetLastError();
     }
+    if (variant == CV_F64 && a.up2 == 2) return launch_conv_up2r(a, s);     // ... with the source patch resident in LDS (conv3_up2r.inc)
     if (variant == CV_F64 && a.up2) {                     // phase-decomposed 2x nearest upsample + 3x3 (four taps per phase)
         const size_t lds = convb_lds_bytes(a, 64, 2, 2);
         dim3 gu(a.tiles_x * a.tiles_y * a.cout_tiles * 4, a.B);
@@ -2413,6 +2415,7 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
 }
 
 #include "conv3_pc.inc"
+#include "conv3_up2r.inc"
 
 // ===========================================================================
 // Thin 1x1 projection (<= 4 output channels, e.g. the decoder's last 64 -> 3 conv): pure streaming, no matrix pipe.
@@ -4748,6 +4751,8 @@ hipError_t init_kernels() {
 #define LNS_SET_LDS(k)                                                                            \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
+    LNS_SET_LDS((conv3_up2r_kernel<true>))
+    LNS_SET_LDS((conv3_up2r_kernel<false>))
     LNS_SET_LDS((conv3_pc_kernel<1, 1>))
     LNS_SET_LDS((conv3_pc_kernel<1, 2>))
     LNS_SET_LDS((conv3_pc_kernel<2, 1>))

@@ -204,6 +204,13 @@ UP2_CASES = [dict(B=2, Cin=64, Cout=64, H=16, W=16, up=(32, 32), mode=(1, 1)), d
              dict(B=3, Cin=64, Cout=64, H=32, W=32, up=(64, 64), mode=(1, 1), bias=False), dict(B=1, Cin=40, Cout=64, H=7, W=15, up=(14, 30), mode=(0, 0), ss=True)]
 for _c in UP2_CASES:
     CONV_CASES.append(dict(k=3, variant=17, **_c))
+# ... its resident-patch form (variant 18: Cin_pad <= 64, one block per source tile walks the four phases)
+UP2R_CASES = [c for c in UP2_CASES if c["Cin"] <= 64] + [
+    dict(B=2, Cin=64, Cout=64, H=64, W=64, up=(128, 128), mode=(1, 1), ss=True, act_in=1),
+    dict(B=2, Cin=24, Cout=64, H=9, W=31, up=(18, 62), mode=(1, 0), ss=True, act_in=1, res=True),
+    dict(B=1, Cin=64, Cout=128, H=16, W=32, up=(32, 64), mode=(0, 0), badd=True, act_out=2)]
+for _c in UP2R_CASES:
+    CONV_CASES.append(dict(k=3, variant=18, **_c))
 # bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel
 # counts, prologue and epilogue features
 for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, Cout=128, H=16, W=16),

@@ -71,6 +71,18 @@ def test_conv_tile_variants_same_bits():
         assert np.array_equal(ys[0], ys[2]), ("variant 16", kw)
 
 
+def test_upsampling_conv_resident_patch_same_bits():
+    """The resident-patch form of the phase-decomposed upsampling conv (op-level variant 18: the split source patch of all
+    channels staged once per source tile, four phases per block) gives the bits of the per-phase form (17)."""
+    _need_gpu()
+    import gpu_checks as gc
+    import numpy as np
+    for kw in gc.UP2R_CASES:
+        y17 = gc.conv_case(k=3, variant=17, seed=9, ret_y=True, **kw)[2]
+        y18 = gc.conv_case(k=3, variant=18, seed=9, ret_y=True, **kw)[2]
+        assert np.array_equal(y17, y18), kw
+
+
 def _domain_cases():
     import gpu_checks as gc
     return list(enumerate(gc.DOMAIN_CASES))

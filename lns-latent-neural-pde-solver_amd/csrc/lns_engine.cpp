@@ -512,10 +512,7 @@ struct Planner {
         a.w = as_ptr<const float>(wt(pk.w_off));
         if (g.variant >= CV_B64) a.wb = as_ptr<const void>(wt(up2 ? pk.wu_off : pk.wb_off));   // CV_B32 included
         a.up2 = up2 ? 1 : 0;
-        // (not for planes of a single pixel tile: there is no second tile to reuse the staged pixels for, and the streaming
-        //  form's epilogue leaves the GroupNorm statistics the next layer folds -- one launch less per propagator step)
-        const bool one_tile = (long)in.H * in.W < GN_TILE_PIXELS && getenv("LNS_GN_NO_RAGGED") == nullptr && getenv("LNS_GN_NO_FOLD") == nullptr;
-        if (g.variant == CV_B1 && pk.Cin_pad <= 64 && g.cout_tiles >= 2 && fuse_pack < 0 && !one_tile) {
+        if (g.variant == CV_B1 && pk.Cin_pad <= 64 && g.cout_tiles >= 2 && fuse_pack < 0) {
             // input-stationary form; the number of cout tiles per block only changes the launch shape, never a bit
             static const bool off = getenv("LNS_CONV1_NO_STATIONARY") != nullptr;
             // ... as many cout tiles per block as still leave this many blocks (three fit a CU): LNS_CONV1S_MIN_BLOCKS

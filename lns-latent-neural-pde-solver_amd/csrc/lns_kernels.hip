@@ -895,7 +895,7 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 // pix[nt]: flat output pixel of this lane in pixel tile nt, or -1.
 // addv: LDS vector [TM] of (bias + per-sample add) of this cout tile, staged in the prologue so that the epilogue
 // does not start with a round trip to L2 (null: read bias / badd from global memory here).
-template <int NT, bool FUSE2, int MT = 2>
+template <int NT, bool FUSE2, int MT = 2, bool STATS = true>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
                                                float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1, long long* ets = nullptr,
@@ -1094,7 +1094,9 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     // every pixel of the tile is valid): the tile goes through LDS as [channel][pixel], four threads per channel
     // take 32 pixels each (two-pass mean / centred second moment in registers) and merge pairwise (Chan et al.).
     constexpr int SROW = 133;                                    // 128 pixels + one pad word per 32 + 1
-    const bool stats = NT == 1 && MT == 2 && a.stat_part != nullptr;     // block-uniform
+    // (STATS = false: kernels the planner never asks for tile statistics -- the input-stationary 1x1 form, which is at its
+    //  register budget -- do not carry the code)
+    const bool stats = STATS && NT == 1 && MT == 2 && a.stat_part != nullptr;     // block-uniform
     float* sb = reinterpret_cast<float*>(lds);
     if (stats) __syncthreads();                                  // main-loop / fused-conv LDS reads are done
     // (am: amax side channel, bit pattern of max |stored value|; the calling kernel publishes it once per block)
@@ -2113,7 +2115,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
         }
         __syncthreads();
         if (++st == nstage) {
-            convb_epilogue<NT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, xinv, am);
+            convb_epilogue<NT, false, MT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, xinv, am);
             st = 0;
             ++ctl;
         }

@@ -127,6 +127,27 @@ def test_device_code_has_no_packed_fp32_arithmetic():
     assert check_isa.count(text, r"global_atomic_umax") > 10          # amax side channel
 
 
+def test_hot_loops_keep_their_instruction_budget():
+    """Regression guard on what the compiler makes of the split-operand K loops (tools/loop_stats.py):
+    per 8-channel stage of the f16x2 3x3 kernel 30 MFMAs beside 13 buffer loads, no 64-bit vector address arithmetic, and a
+    VALU count within a margin of the measured one (40 without prologue, 75 with GroupNorm + Swish, 203 with the exact GELU)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    import loop_stats
+    from lns_amd import _lib
+    text = check_isa.disassemble(_lib.LIB_PATH)
+    segs = loop_stats.segments(text, "conv3_bf16x3_kernelILi1ELi1ELb0ELi2ELi2ELi9E", 30)
+    assert len(segs) == 4                                   # the four prologue modes of the nine-tap f16x2 kernel
+    valu = sorted(c["valu"] for _, c, _ in segs)
+    for _, c, v in segs:
+        assert c["mfma"] == 30 and c["vmem_load"] == 13 and c["ds_write"] == 7
+        assert v.get("v_lshl_add_u64", 0) == 0 and v.get("v_mad_i64_i32", 0) == 0
+    assert valu[0] <= 50 and valu[2] <= 90 and valu[3] <= 230, valu
+    segs1 = loop_stats.segments(text, "conv1_bf16x3_kernelILb1ELb0", 12)        # streaming 1x1 kernel, 8-byte loads
+    assert segs1 and min(c["valu"] - v.get("v_mov_b32_e32", 0) for _, c, v in segs1) <= 70
+
+
 def test_set_option_validates_names_and_ranges():
     from lns_amd import config, engine, _lib
     e = engine.Engine(engine.make_config(config.preset("ns2d_mini"), ae_prefix="vq_ae.", prop_prefix="propagator."))

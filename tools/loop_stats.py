@@ -28,28 +28,38 @@ def classify(op):
     return op
 
 
-def main():
-    text = check_isa.disassemble(sys.argv[1])
-    sub = sys.argv[2]
-    min_mfma = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+def segments(text, sub, min_mfma=12):
+    """[(kernel symbol, {class: count}, Counter of VALU opcodes)] for every barrier-delimited segment with >= min_mfma MFMAs
+    of the kernels whose symbol contains `sub`."""
+    out = []
     for m in re.finditer(r"^[0-9a-f]+ <([^>]+)>:$", text, re.M):
         if sub not in m.group(1):
             continue
         end = re.search(r"^[0-9a-f]+ <[^>]+>:$", text[m.end():], re.M)
         body = text[m.end(): m.end() + end.start()] if end else text[m.end():]
         ops = [l.split()[0] for l in body.splitlines() if l.strip() and not l.strip().startswith("//")]
-        print(m.group(1), len(ops), "instructions")
         seg = []
         for op in ops + ["s_barrier"]:
             if op == "s_barrier":
                 c = collections.Counter(classify(o) for o in seg)
                 if c["mfma"] >= min_mfma:
-                    v = collections.Counter(o for o in seg if classify(o) == "valu")
-                    print("  ", {k: c[k] for k in ("mfma", "valu", "trans", "salu", "ds_read", "ds_write", "vmem_load", "waitcnt", "acc_mov") if c[k]})
-                    print("     ", v.most_common(12))
+                    out.append((m.group(1), dict(c), collections.Counter(o for o in seg if classify(o) == "valu")))
                 seg = []
             else:
                 seg.append(op)
+    return out
+
+
+def main():
+    text = check_isa.disassemble(sys.argv[1])
+    min_mfma = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    last = None
+    for name, c, v in segments(text, sys.argv[2], min_mfma):
+        if name != last:
+            print(name)
+            last = name
+        print("  ", {k: c[k] for k in ("mfma", "valu", "trans", "salu", "ds_read", "ds_write", "vmem_load", "waitcnt", "acc_mov") if c.get(k)})
+        print("     ", v.most_common(12))
 
 
 if __name__ == "__main__":

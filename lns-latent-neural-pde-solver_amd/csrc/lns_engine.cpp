@@ -185,18 +185,20 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
         g.PH = tmp.PH; g.PW = tmp.PW; g.sel_kc_log2 = best_kc;
         found = true;
         static const long min_blocks = getenv("LNS_CONV_MIN_BLOCKS") ? atol(getenv("LNS_CONV_MIN_BLOCKS")) : 128;
-        if (cands[ci] == CV_B64 && Cout >= 64 && !need_wgm1) {
+        if (cands[ci] == CV_B64 && Cout >= 64 && !need_wgm1 && force_variant < 0) {
             // 32-cout tiles (same accumulation order, same bits) when 64-cout tiles give fewer blocks than this.
             // Measured on NS2d-128 (16x16 latent layers, 256 -> 512 blocks): no gain (17.9k vs 18.7k
             // trajectory-steps/s), so the default is off; kept as a tuning knob and covered by the kernel tests.
             static const long want = getenv("LNS_CONVB32_BELOW") ? atol(getenv("LNS_CONVB32_BELOW")) : 0;
             if (blocks < want) { g.variant = CV_B32; g.cout_tiles = (Cout + 31) / 32; }
         }
-        if (cands[ci] == CV_F64 && Cout >= 64 && !need_wgm1) {
-            // the same for the f16x2 form (two blocks per CU on the 16x16 latent layers).  Measured at the end of
-            // round 1: 3x3 class 83.3 -> 84.3 ms, rollout 144.3 -> 148.1 ms (every block still stages and splits the whole
-            // patch), so the default stays off; tuning knob, covered by the kernel tests (variant 13).
-            static const long wantf = getenv("LNS_CONVF32_BELOW") ? atol(getenv("LNS_CONVF32_BELOW")) : 0;
+        if (cands[ci] == CV_F64 && Cout >= 64 && !need_wgm1 && force_variant < 0) {
+            // the same for the f16x2 form.  On 256-block launches (the 16x16 latent layers of NS2d at B = 64) it measured
+            // neutral to slower (round 1: rollout 144.3 -> 148.1 ms; round 3: 22.6 -> 22.9 us per layer -- every block still
+            // stages and splits the whole patch), but launches that leave three quarters of the CUs idle gain: the 7 x 15
+            // latent layers of the two-phase models at B = 32 (64 blocks) 19.7 -> 15.3 us, dilated 20.5 -> 17.8
+            // (tools/conv_time.py lat_tp / lat_tp_d4, variant 13).  Same bits either way, so the batch may decide.
+            static const long wantf = getenv("LNS_CONVF32_BELOW") ? atol(getenv("LNS_CONVF32_BELOW")) : 100;
             if (blocks < wantf) { g.variant = CV_F32; g.cout_tiles = (Cout + 31) / 32; }
         }
         if (cands[ci] >= CV_B64) break;                        // never fall through to another kernel family by launch size
@@ -424,7 +426,7 @@ struct Planner {
         const bool ragged1 = !no_fold && !no_ragged && prod && prod->type == OP_CONV && !prod->conv.up2 &&
                              prod->conv.tiles_x * prod->conv.tiles_y == 1 && x.H * x.W < GN_TILE_PIXELS;
         const bool prod_ok = prod && prod->type == OP_CONV &&
-                             (prod->variant == CV_F64 || prod->variant == CV_B64 ||
+                             (prod->variant == CV_F64 || prod->variant == CV_F32 || prod->variant == CV_B64 ||
                               (prod->variant == CV_B1 && !no_fold && prod->conv.ct_per_block == 0 && !prod->conv.w2 &&
                                ((x.H * x.W) % GN_TILE_PIXELS == 0 || ragged1)));
         if (stat_scratch && (!premul || ragged1) && prod_ok &&
@@ -485,8 +487,12 @@ struct Planner {
         if (!conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, -1, fuse_pack >= 0,
                            pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok))
             throw std::runtime_error("no conv tiling for " + name);
+        if (up2 && g.variant == CV_F32 &&          // (a small launch: the phase form exists for 64-cout tiles only)
+            !conv_geometry(g, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, CV_F64, fuse_pack >= 0,
+                           pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok))
+            throw std::runtime_error("no conv tiling for " + name);
         if (up2 && g.variant != CV_F64) throw std::runtime_error("phase form needs the f16x2 64-cout tiles: " + name);
-        if (in.act == ACT_GELU && (g.variant != CV_F64 || up2 || fuse_pack >= 0))
+        if (in.act == ACT_GELU && ((g.variant != CV_F64 && g.variant != CV_F32) || up2 || fuse_pack >= 0))
             throw std::runtime_error("GELU prologue is only built into the f16x2 3x3 kernel: " + name);
         if (up2) { g.Hout = 2 * in.H; g.Wout = 2 * in.W; }
         const ConvVariantInfo vi = conv_variant_info(g.variant);
@@ -526,7 +532,7 @@ struct Planner {
         if (in.gn_lazy >= 0 && !lazy_done[in.gn_lazy]) {
             // GroupNorm whose finalize step is still pending: the split-operand kernels merge the producer's tile partials in
             // their own prologue (no launch); every other consumer gets the finalize op now
-            if (g.variant == CV_F64 || g.variant == CV_B1) {
+            if (g.variant == CV_F64 || g.variant == CV_F32 || g.variant == CV_B1) {
                 const Op& lo = lazy_ops[in.gn_lazy];
                 a.ss = nullptr;
                 a.gn_part = lo.gn_tile_part; a.gn_tiles = lo.gn_tiles; a.gn_groups = lo.gn.groups; a.gn_eps = lo.gn.eps;

@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     constexpr int SROW = 133;                                    // 128 pixels + one pad word per 32 + 1
     // (STATS = false: kernels the planner never asks for tile statistics -- the input-stationary 1x1 form, which is at its
     //  register budget -- do not carry the code)
-    const bool stats = STATS && NT == 1 && MT == 2 && a.stat_part != nullptr;     // block-uniform
+    const bool stats = STATS && NT == 1 && a.stat_part != nullptr;     // block-uniform (32-cout tiles: half the threads)
     float* sb = reinterpret_cast<float*>(lds);
     if (stats) __syncthreads();                                  // main-loop / fused-conv LDS reads are done
     // (am: amax side channel, bit pattern of max |stored value|; the calling kernel publishes it once per block)
@@ -1202,6 +1202,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
         if (a.stat_count && (tid & 63) == 0) smask[tid >> 6] = (unsigned)have;
         __syncthreads();
         const int c = tid >> 2, q = tid & 3;
+        if (c < TM) {            // (whole waves: 64-cout tiles keep all four busy, 32-cout tiles two)
         const float* row = sb + c * SROW + q * 33;
         float v[32];
 #pragma unroll
@@ -1259,6 +1260,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             const int tile = sp_tile >= 0 ? sp_tile : (int)blockIdx.x / a.cout_tiles, ntiles = a.tiles_x * a.tiles_y * tile_mult;
             float* pp = a.stat_part + (((long)b * ntiles + tile) * a.Cout + co) * 2;
             pp[0] = mean; pp[1] = m2;
+        }
         }
     }
 }
@@ -1634,8 +1636,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         }
     };
     if (pro_mode == 2) k_loop(std::integral_constant<int, 2>{});
-    else if (pro_mode == 3) {                            // (f16x2 64 x 128 tiles only: the planner's rule)
-        if constexpr (SPL == 2 && NTAP == 9 && !FUSE2 && MT == 2 && NT == 1) k_loop(std::integral_constant<int, 3>{});
+    else if (pro_mode == 3) {                            // (f16x2 128-pixel tiles, 64 or 32 couts: the planner's rule)
+        if constexpr (SPL == 2 && NTAP == 9 && !FUSE2 && NT == 1) k_loop(std::integral_constant<int, 3>{});
     }
     else if (pro_mode == 1) k_loop(std::integral_constant<int, 1>{});
     else k_loop(std::integral_constant<int, 0>{});

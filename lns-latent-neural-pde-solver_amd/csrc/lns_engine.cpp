@@ -961,7 +961,7 @@ struct Planner {
         emit_gn(h2, 1, 1e-5f, l.c_g, l.c_b, 0, q + ".cond_conv1.0");
         // GroupNorm -> GELU -> conv: the f16x2 3x3 kernel applies both in its prologue (mode 3); any other kernel gets the
         // materialised tensor (round 2's form, LNS_NO_GELU_PROLOGUE=1)
-        static const bool no_gelu_pro = getenv("LNS_NO_GELU_PROLOGUE") != nullptr;
+        static const bool no_gelu_pro = getenv("LNS_NO_GELU_PROLOGUE") != nullptr || getenv("LNS_CONV_FP32_MFMA") != nullptr;   // (strict-fp32 runs have no split-operand kernels)
         const ConvPack& cpk = e->packs[l.c_conv];
         TRef x1;
         if (!no_gelu_pro && cpk.has_wb && cpk.f16 && cpk.cout > 32) {

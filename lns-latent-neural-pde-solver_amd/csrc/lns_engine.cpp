@@ -2070,6 +2070,9 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     OPCHK(init_kernels());
     const bool stationary = tile_variant == 8;      // test code: 1x1 bf16x3 kernel in its input-stationary form
     if (stationary) tile_variant = CV_B1;
+    const bool w8 = tile_variant == 19;             // test code: f16x2 3x3 kernel in its 8-wave form (conv3_w8.inc)
+    const bool forced = tile_variant >= 0;
+    if (w8) tile_variant = CV_F64;
     const bool up2r = tile_variant == 18;           // test code: ... its resident-patch form (conv3_up2r.inc)
     const bool up2 = tile_variant == 17 || up2r;    // test code: f16x2 3x3 kernel, phase form of an exactly-2x nearest upsample
     if (up2) {
@@ -2157,6 +2160,7 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
         a.up2 = 2;
         if (!convur_fits(a)) return LNS_EINVAL;
     }
+    a.w8 = w8 ? 1 : (forced ? -1 : 0);              // a forced tile variant means that kernel
     if (stationary) {
         if (pk.Cin_pad > 64) return LNS_EINVAL;
         a.ct_per_block = g.cout_tiles < 3 ? g.cout_tiles : 3;

@@ -65,6 +65,7 @@ struct ConvArgs {
     // padded position p -> p - map_pad; outside [0, size): wrapped once (map_circ bit) or none; p >= map_ext: none.
     // Index 0 = rows, 1 = columns.  The tables stay valid either way (every other kernel reads them).
     int map_arith, map_circ[2], map_pad[2], map_ext[2];
+    int w8;                // CV_F64 launches: 0 = the 8-wave form (conv3_w8.inc) when the launch is small, 1 = always, -1 = never
     int ct_per_block;      // 1x1 bf16x3, input-stationary form: cout tiles walked by one block (0 = streaming form)
     // 3x3 split-operand kernel, 128-pixel tiles that cover the plane exactly: per (sample, pixel tile, channel)
     // (mean, centred second moment) of the stored output, [B][tiles][Cout][2]; the following GroupNorm merges them

@@ -146,7 +146,9 @@ __device__ __forceinline__ float wave_sum(float v);
 // <= 64) every thread sums its channel over the tiles and the group over its aligned lanes by xor shuffles.  Equal-count
 // merge (every partial covers 128 pixels), two-pass like gn_tile_finalize_kernel; all blocks of a sample run the same
 // code on the same data, so the table is bit-identical in all of them.  Called by all 256 threads; uses wmax as scratch.
-__device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid) {
+// `active` = false: a thread that only keeps the block's barriers company (the second wave group of conv3_w8_kernel: `tid` is
+// the index inside a group of 256, the sums are those of the first group alone -- the bits of a 256-thread block).
+__device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid, bool active = true) {
     const int C = a.Cin, tiles = a.gn_tiles;
     const float* pb = a.gn_part + (long)b * tiles * C * 2;
     float* red = reinterpret_cast<float*>(wmax);
@@ -156,13 +158,13 @@ __device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b,
         const float* pm = a.gn_premul + (long)b * C;
         const int E = tiles * C;
         float sm = 0.0f;
-        for (int i = tid; i < E; i += 256) sm += pm[i % C] * pb[2 * i];
+        for (int i = tid; active && i < E; i += 256) sm += pm[i % C] * pb[2 * i];
         const float mean = block_sum_256(sm, red) / (float)E;
         float m2 = 0.0f;
-        for (int i = tid; i < E; i += 256) { const float p = pm[i % C], d = p * pb[2 * i] - mean; m2 += p * p * pb[2 * i + 1] + cnt * d * d; }
+        for (int i = tid; active && i < E; i += 256) { const float p = pm[i % C], d = p * pb[2 * i] - mean; m2 += p * p * pb[2 * i + 1] + cnt * d * d; }
         const float var = block_sum_256(m2, red) / (cnt * (float)E);
         const float rstd = 1.0f / sqrtf(var + a.gn_eps);
-        for (int c = tid; c < a.Cin_pad; c += 256) {
+        for (int c = tid; active && c < a.Cin_pad; c += 256) {
             float2 st = make_float2(1.0f, 0.0f);
             if (c < C) {
                 const float ga = a.gn_gamma ? a.gn_gamma[c] : 1.0f, be = a.gn_beta ? a.gn_beta[c] : 0.0f;
@@ -173,13 +175,13 @@ __device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b,
     } else if (a.gn_groups == 1) {
         const int E = tiles * C;
         float sm = 0.0f;
-        for (int i = tid; i < E; i += 256) sm += pb[2 * i];
+        for (int i = tid; active && i < E; i += 256) sm += pb[2 * i];
         const float mean = block_sum_256(sm, red) / (float)E;
         float m2 = 0.0f;
-        for (int i = tid; i < E; i += 256) { const float d = pb[2 * i] - mean; m2 += pb[2 * i + 1] + cnt * d * d; }
+        for (int i = tid; active && i < E; i += 256) { const float d = pb[2 * i] - mean; m2 += pb[2 * i + 1] + cnt * d * d; }
         const float var = block_sum_256(m2, red) / (cnt * (float)E);
         const float rstd = 1.0f / sqrtf(var + a.gn_eps);
-        for (int c = tid; c < a.Cin_pad; c += 256) {
+        for (int c = tid; active && c < a.Cin_pad; c += 256) {
             float2 st = make_float2(1.0f, 0.0f);
             if (c < C) {
                 const float ga = a.gn_gamma ? a.gn_gamma[c] : 1.0f, be = a.gn_beta ? a.gn_beta[c] : 0.0f;
@@ -191,7 +193,7 @@ __device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b,
         const int cg = C / a.gn_groups;                    // power of two <= 64: a group is an aligned run of lanes
         for (int c0 = 0; c0 < a.Cin_pad; c0 += 256) {
             const int c = c0 + tid;
-            const bool live = c < C;
+            const bool live = active && c < C;
             float sm = 0.0f;
             if (live) for (int t = 0; t < tiles; ++t) sm += pb[((long)t * C + c) * 2];
             for (int o = 1; o < cg; o <<= 1) sm += __shfl_xor(sm, o);
@@ -200,7 +202,7 @@ __device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b,
             if (live) for (int t = 0; t < tiles; ++t) { const float* pp = pb + ((long)t * C + c) * 2; const float d = pp[0] - mean; m2 += pp[1] + cnt * d * d; }
             for (int o = 1; o < cg; o <<= 1) m2 += __shfl_xor(m2, o);
             const float rstd = 1.0f / sqrtf(m2 / (cnt * (float)(tiles * cg)) + a.gn_eps);
-            if (c < a.Cin_pad) {
+            if (active && c < a.Cin_pad) {
                 float2 st = make_float2(1.0f, 0.0f);
                 if (live) {
                     const float ga = a.gn_gamma ? a.gn_gamma[c] : 1.0f, be = a.gn_beta ? a.gn_beta[c] : 0.0f;
@@ -2356,6 +2358,8 @@ void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, i
 }
 
 hipError_t launch_conv_up2r(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_w8(const ConvArgs& a, hipStream_t s);
+bool convw8_fits(const ConvArgs& a);
 hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     if (!convb_fits(a)) return hipErrorInvalidValue;
     if (cv_is_f16x2_3x3(variant) && !has_act_bound(a)) return hipErrorInvalidValue;
@@ -2382,6 +2386,12 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     if (a.up2) return hipErrorInvalidValue;
+    if (variant == CV_F64 && !a.w2 && a.w8 >= 0) {        // small launches: the 8-wave form (conv3_w8.inc) -- measured no faster,
+        static const long w8_below = getenv("LNS_CONV_W8_BELOW") ? atol(getenv("LNS_CONV_W8_BELOW")) : 0;      // so opt-in only
+        const long blocks = (long)a.tiles_x * a.tiles_y * a.cout_tiles * a.B;
+        if ((a.w8 == 1 || blocks < w8_below) && convw8_fits(a)) return launch_conv_w8(a, s);
+        if (a.w8 == 1) return hipErrorInvalidValue;
+    }
     if (variant == CV_F64) {                              // two-term fp16 split
         const size_t lds = convb_lds_bytes(a, 64, 2, 2);
         if (a.w2) {
@@ -2420,6 +2430,7 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
 
 #include "conv3_pc.inc"
 #include "conv3_up2r.inc"
+#include "conv3_w8.inc"
 
 // ===========================================================================
 // Thin 1x1 projection (<= 4 output channels, e.g. the decoder's last 64 -> 3 conv): pure streaming, no matrix pipe.
@@ -4755,6 +4766,8 @@ hipError_t init_kernels() {
 #define LNS_SET_LDS(k)                                                                            \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
+    LNS_SET_LDS(conv3_w8_kernel<1>)
+    LNS_SET_LDS(conv3_w8_kernel<2>)
     LNS_SET_LDS((conv3_up2r_kernel<true>))
     LNS_SET_LDS((conv3_up2r_kernel<false>))
     LNS_SET_LDS((conv3_pc_kernel<1, 1>))

@@ -211,6 +211,10 @@ UP2R_CASES = [c for c in UP2_CASES if c["Cin"] <= 64] + [
     dict(B=1, Cin=64, Cout=128, H=16, W=32, up=(32, 64), mode=(0, 0), badd=True, act_out=2)]
 for _c in UP2R_CASES:
     CONV_CASES.append(dict(k=3, variant=18, **_c))
+# f16x2 3x3 kernel, 8-wave form for small launches (variant 19)
+for _c in [dict(B=2, Cin=128, Cout=128, H=16, W=16, ss=True, act_in=1, mode=(1, 1)), dict(B=2, Cin=128, Cout=128, H=7, W=15, ss=True, mode=(0, 0), badd=True),
+           dict(B=2, Cin=40, Cout=100, H=21, W=37, ss=True, act_in=1, res=True, mode=(0, 0)), dict(B=1, Cin=64, Cout=64, H=16, W=16, dil=2, mode=(1, 1), act_out=2)]:
+    CONV_CASES.append(dict(k=3, variant=19, **_c))
 # bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel
 # counts, prologue and epilogue features
 for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, Cout=128, H=16, W=16),

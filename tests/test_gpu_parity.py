@@ -69,6 +69,16 @@ def test_conv_tile_variants_same_bits():
         ys = [gc.conv_case(k=3, variant=v, seed=6, ret_y=True, **kw)[2] for v in (11, 15, 16)]
         assert np.array_equal(ys[0], ys[1]), ("variant 15", kw)
         assert np.array_equal(ys[0], ys[2]), ("variant 16", kw)
+    # the 8-wave form for small launches (19: two wave groups of 32 couts share one patch and one slab)
+    for kw in (dict(B=2, Cin=64, Cout=64, H=16, W=16, ss=True, act_in=1, res=True, mode=(1, 1)),
+               dict(B=2, Cin=72, Cout=100, H=20, W=36, ss=True, act_in=1, badd=True, mode=(0, 0)),
+               dict(B=3, Cin=128, Cout=128, H=7, W=15, ss=True, act_out=2, mode=(0, 0)),
+               dict(B=2, Cin=128, Cout=128, H=16, W=16, dil=4, ss=True, act_in=1, act_out=2, mode=(1, 1)),
+               dict(B=2, Cin=40, Cout=64, H=12, W=24, mode=(0, 1), bias=False),
+               dict(B=1, Cin=128, Cout=192, H=32, W=32, ss=True, act_in=1, res=True, mode=(1, 1))):
+        y11 = gc.conv_case(k=3, variant=11, seed=8, ret_y=True, **kw)[2]
+        y19 = gc.conv_case(k=3, variant=19, seed=8, ret_y=True, **kw)[2]
+        assert np.array_equal(y11, y19), ("variant 19", kw)
 
 
 def test_upsampling_conv_resident_patch_same_bits():

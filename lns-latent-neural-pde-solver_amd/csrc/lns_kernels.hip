@@ -1556,10 +1556,17 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             const int cw = c0 + KC < last ? c0 + KC : last;
             const int cl2 = c0 + 2 * KC < last ? c0 + 2 * KC : last;
             uint4 af[2][SPL][MT], bf[2][SPL][NT];
+#if defined(LNS_KNOCK) && (LNS_KNOCK & 2)     // ... no fragment reads either (one set read once per stage)
             load_frags(0, Xs, Ws, af[0], bf[0]);
+            load_frags(1, Xs, Ws, af[1], bf[1]);
+#else
+            load_frags(0, Xs, Ws, af[0], bf[0]);
+#endif
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 2))
                 if (j + 1 < NJ) load_frags(j + 1, Xs, Ws, af[(j + 1) & 1], bf[(j + 1) & 1]);
+#endif
                 // this k-step transforms pair j of stage cw with the table entries read one k-step ago; the entries of
                 // the next pair to be transformed (pair j+1, or pair 0 of the following stage) are requested now
                 const float4 stu = stq;
@@ -1587,7 +1594,11 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                     LNS_BX3(acc_lo, 1, 0)
                 }
 #undef LNS_BX3
+#if defined(LNS_KNOCK) && (LNS_KNOCK & 1)     // timing what-if (garbage results): no staging inside the K loop
+                if (false) {
+#else
                 if (UP2) {       // two k-steps per stage: two channel pairs and half of the (small) slab each
+#endif
 #pragma unroll
                     for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -1605,7 +1616,11 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
                         for (int u = 0; u < NU; ++u) flush_unit(u, Xn);
                     }
+#if defined(LNS_KNOCK) && (LNS_KNOCK & 1)
+                } else if (false) {
+#else
                 } else if (j < 4) {
+#endif
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
                         split_pair_r(mode_tag, u, j, stu);
@@ -1618,8 +1633,10 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                             load_w(i, cl2);
                         }
                 } else {
+#if !(defined(LNS_KNOCK) && (LNS_KNOCK & 1))
 #pragma unroll
                     for (int u = 0; u < NU; ++u) flush_unit(u, Xn);
+#endif
                 }
                 // schedule: ALL LDS reads of the k-step first (next k-step's fragments + next pair's table entries:
                 // nothing in this k-step consumes them), then after each MFMA a few of the step's other instructions

@@ -425,11 +425,16 @@ struct Planner {
         static const bool no_ragged = getenv("LNS_GN_NO_RAGGED") != nullptr;
         const bool ragged1 = !no_fold && !no_ragged && prod && prod->type == OP_CONV && !prod->conv.up2 &&
                              prod->conv.tiles_x * prod->conv.tiles_y == 1 && x.H * x.W < GN_TILE_PIXELS;
+        // ... and planes whose 128-pixel tiles do not cover them exactly (14 x 30, 28 x 60, 61 x 121 in the two-phase decoder):
+        // every block counts its own valid pixels, the finalize kernel merges partials of unequal counts (never folded)
+        static const bool no_ragged_tiles = getenv("LNS_GN_NO_RAGGED_TILES") != nullptr;
+        const bool raggedN = !no_fold && !no_ragged && !no_ragged_tiles && prod && prod->type == OP_CONV && !prod->conv.up2 && !ragged1 &&
+                             x.H * x.W > GN_TILE_PIXELS;
         const bool prod_ok = prod && prod->type == OP_CONV &&
                              (prod->variant == CV_F64 || prod->variant == CV_F32 || prod->variant == CV_B64 ||
                               (prod->variant == CV_B1 && !no_fold && prod->conv.ct_per_block == 0 && !prod->conv.w2 &&
-                               ((x.H * x.W) % GN_TILE_PIXELS == 0 || ragged1)));
-        if (stat_scratch && (!premul || ragged1) && prod_ok &&
+                               ((x.H * x.W) % GN_TILE_PIXELS == 0 || ragged1 || raggedN)));
+        if (stat_scratch && (!premul || ragged1 || raggedN) && prod_ok &&
             prod->conv.y == as_ptr<float>(x.ptr) && prod->conv.Cout == x.C && ((long)x.H * x.W >= min_hw || ragged1)) {
             const ConvArgs& c = prod->conv;
             const int BW = 1 << c.bw_log2, BH = GN_TILE_PIXELS / BW;
@@ -439,11 +444,12 @@ struct Planner {
             // the 128-pixel tiles cover the plane exactly (1x1: tiles of 128 consecutive pixels)
             const bool exact = c.ks == 1 ? (c.tiles_x * GN_TILE_PIXELS == x.H * x.W && c.tiles_y == 1)
                                          : (c.tiles_x * BW * um == x.W && c.tiles_y * BH * um == x.H);
-            if ((exact || ragged1) && (size_t)B * tiles * x.C * 8 <= stat_cap) {
+            if ((exact || ragged1 || raggedN) && (size_t)B * tiles * x.C * 8 <= stat_cap) {
                 // foldable into the consumer's prologue: few tiles, one group or power-of-two groups within a wave
                 const int cg = x.C / groups;
                 static const int fold_tiles = getenv("LNS_GN_FOLD_TILES") ? atoi(getenv("LNS_GN_FOLD_TILES")) : 2;
-                const bool foldable = !no_fold && tiles <= fold_tiles && x.C <= 512 && (groups == 1 || (cg <= 64 && (cg & (cg - 1)) == 0));
+                const bool foldable = !no_fold && (exact || ragged1) && tiles <= fold_tiles && x.C <= 512 &&
+                                      (groups == 1 || (cg <= 64 && (cg & (cg - 1)) == 0));
                 const int li = (int)lazy_ops.size();
                 lazy_done.push_back(0); lazy_folded.push_back(0);
                 const uint64_t region = take_stat_region(name, li);
@@ -452,6 +458,11 @@ struct Planner {
                 op.gn_tiles = tiles;
                 op.gn_count = ragged1 ? x.H * x.W : GN_TILE_PIXELS;
                 if (ragged1) prod->conv.stat_count = x.H * x.W;
+                if (!exact && !ragged1) {       // raggedN
+                    op.gn_count = -1;
+                    op.gn_geom = GnTileGeom{c.tiles_x, c.bw_log2, x.H, x.W, c.ks == 1 ? 1 : 0};
+                    prod->conv.stat_count = -1;
+                }
                 op.bytes = 2.0 * B * tiles * x.C * 8;
                 lazy_ops.push_back(op);
                 if (foldable) { x.gn_lazy = li; return; }
@@ -1378,7 +1389,8 @@ struct Runner {
                     if (op.gn_tiles) {
                         const float* tp = op.gn_tile_part;
                         fix(tp, B);
-                        rc = launch_gn_tile_finalize(a, tp, op.gn_tiles, op.gn_count ? op.gn_count : GN_TILE_PIXELS, stream);
+                        rc = launch_gn_tile_finalize(a, tp, op.gn_tiles, op.gn_count < 0 ? 0 : (op.gn_count ? op.gn_count : GN_TILE_PIXELS),
+                                                     op.gn_geom, stream);
                         break;
                     }
                     rc = launch_gn_stats(a, a.ss + (size_t)a.B * a.C * 2, stream);

@@ -87,7 +87,8 @@ struct Op {
     GnStatsArgs gn;
     const float* gn_tile_part = nullptr;   // GroupNorm fed by a convolution's per-tile partials (tagged pointer)
     int gn_tiles = 0;
-    int gn_count = 0;           // pixels behind every tile partial (GN_TILE_PIXELS, or the plane of a ragged single tile)
+    int gn_count = 0;           // pixels behind every tile partial (GN_TILE_PIXELS, or the plane of a ragged single tile);
+    GnTileGeom gn_geom = {0, 0, 0, 0, 0};   // -1: ragged tiles of a larger plane, counts from gn_geom (unequal-count merge)
     LnPeArgs ln;
     AttnArgs at;
     FaPoolArgs fp;

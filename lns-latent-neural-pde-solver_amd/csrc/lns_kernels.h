@@ -57,7 +57,8 @@ struct ConvArgs {
     // itself (same code, same order: same bits), which removes the statistics / finalize launch from the dependency chain
     const float* gn_part; const float* gn_gamma; const float* gn_beta; int gn_tiles, gn_groups; float gn_eps;
     // ragged single tile (planes below 128 pixels, e.g. the 7 x 15 latents of the two-phase models): the producer's
-    // partial covers stat_count valid pixels (0 = the full 128), the consumer divides by gn_count (0 = 128);
+    // partial covers stat_count valid pixels (0 = the full 128; -1 = ragged tiles of a larger plane: every block counts its
+    // own valid pixels, merged by gn_tile_finalize_kernel with unequal counts), the consumer divides by gn_count (0 = 128);
     // gn_premul [B][Cin] or null: statistics of x * premul, the GroupNorm's per-sample channel multiplier
     int stat_count, gn_count; const float* gn_premul;
     // split-operand 3x3 kernel: source maps computed in the kernel instead of read from rowmap / colmap (one memory latency
@@ -163,7 +164,10 @@ bool gn_stats_two_stage(const GnStatsArgs& a);
 hipError_t launch_gn_stats(const GnStatsArgs& a, float* part, hipStream_t s);
 // GroupNorm scale/shift from the per-tile partials a convolution epilogue left (ConvArgs::stat_part); a.x unused
 #define GN_TILE_PIXELS 128
-hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, int count, hipStream_t s);
+// count > 0: every partial covers that many pixels.  count == 0: ragged tiling (GnTileGeom): tile t covers
+// min(BH, H - ty BH) x min(BW, W - tx BW) pixels (3x3 producers) or min(128, HW - 128 t) (1x1 producers); unequal-count merge.
+struct GnTileGeom { int tiles_x, bw_log2, H, W, flat; };
+hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, int count, GnTileGeom geom, hipStream_t s);
 
 // LayerNorm over channels of a channel-major token tensor + positional embedding
 struct LnPeArgs {

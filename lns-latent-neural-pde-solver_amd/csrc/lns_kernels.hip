@@ -1223,7 +1223,10 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             float sm = (s0 + s1) + (s2 + s3);
             sm += dpp_quad<0xB1>(sm);
             sm += dpp_quad<0x4E>(sm);
-            mean = sm / (float)a.stat_count;
+            // (one ragged tile: the plane's pixel count; ragged tiles of a larger plane: this tile's own valid pixels)
+            const float nval = a.stat_count > 0 ? (float)a.stat_count
+                                                : (float)(__popc(smask[0]) + __popc(smask[1]) + __popc(smask[2]) + __popc(smask[3]));
+            mean = sm / nval;
             float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
 #pragma unroll
             for (int i = 0; i < 32; i += 4) {
@@ -2741,6 +2744,45 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnStatsArgs a, const fl
 // GroupNorm scale/shift from the per-tile (mean, M2) partials a convolution epilogue left: [B][tiles][C][2], every
 // partial over GN_TILE_PIXELS values.  One block per (group, sample); fixed order, exact merge of equal-count sets.
 // `count` pixels behind every partial (GN_TILE_PIXELS, or the plane of a ragged single tile); a.premul as in gn_stats_kernel.
+__device__ __forceinline__ float gn_tile_count(const GnTileGeom& q, int t) {
+    if (q.flat) return (float)min(GN_TILE_PIXELS, q.H * q.W - t * GN_TILE_PIXELS);
+    const int BW = 1 << q.bw_log2, BH = GN_TILE_PIXELS >> q.bw_log2, ty = t / q.tiles_x, tx = t - ty * q.tiles_x;
+    return (float)(min(BH, q.H - ty * BH) * min(BW, q.W - tx * BW));
+}
+// ragged tiling: partials over unequal pixel counts (fixed order; Chan et al. with weights)
+__global__ __launch_bounds__(256) void gn_tile_finalize_ragged_kernel(GnStatsArgs a, const float* part, int tiles, GnTileGeom q) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cg = a.C / a.groups;
+    const int E = tiles * cg;
+    const float* pb = part + (long)b * tiles * a.C * 2;
+    const float* pm = a.premul ? a.premul + (long)b * a.C + g * cg : nullptr;
+    const float N = (float)cg * (float)(q.H * q.W);
+    float sm = 0.0f;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const int t = i / cg, c = i - t * cg;
+        const float mc = pb[((long)t * a.C + g * cg + c) * 2];
+        sm += gn_tile_count(q, t) * (pm ? pm[c] * mc : mc);
+    }
+    const float mean = block_sum_256(sm, red) / N;
+    float m2 = 0.0f;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const int t = i / cg, c = i - t * cg;
+        const float* pp = pb + ((long)t * a.C + g * cg + c) * 2;
+        const float n = gn_tile_count(q, t), p = pm ? pm[c] : 1.0f, d = p * pp[0] - mean;
+        m2 += p * p * pp[1] + n * d * d;
+    }
+    const float var = block_sum_256(m2, red) / N;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    for (int c = threadIdx.x; c < cg; c += 256) {
+        const int ch = g * cg + c;
+        const float ga = a.gamma ? a.gamma[ch] : 1.0f;
+        const float be = a.beta ? a.beta[ch] : 0.0f;
+        a.ss[((long)b * a.C + ch) * 2] = pm ? rstd * ga * pm[c] : rstd * ga;
+        a.ss[((long)b * a.C + ch) * 2 + 1] = be - mean * rstd * ga;
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_tile_finalize_kernel(GnStatsArgs a, const float* part, int tiles, int count) {
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y;
@@ -2774,8 +2816,9 @@ __global__ __launch_bounds__(256) void gn_tile_finalize_kernel(GnStatsArgs a, co
     }
 }
 
-hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, int count, hipStream_t s) {
-    hipLaunchKernelGGL(gn_tile_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a, tile_part, tiles, count);
+hipError_t launch_gn_tile_finalize(const GnStatsArgs& a, const float* tile_part, int tiles, int count, GnTileGeom geom, hipStream_t s) {
+    if (count > 0) hipLaunchKernelGGL(gn_tile_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a, tile_part, tiles, count);
+    else hipLaunchKernelGGL(gn_tile_finalize_ragged_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a, tile_part, tiles, geom);
     return hipGetLastError();
 }
 

@@ -19,3 +19,13 @@ for to_x in (True, False, True, False):
     for _ in range(3):
         t0 = time.perf_counter(); eng.rollout(x, T, param=param, to_x=to_x); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print("to_x=%s: %.2f ms" % (to_x, min(ts) * 1e3))
+# the decode alone: T decodes of B latents, back to back on one stream
+z = model.x_to_z(x, param) if param is not None and getattr(args, "cond_encoder", False) else model.x_to_z(x)
+model.z_to_x(z); torch.cuda.synchronize()
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    for _ in range(T):
+        model.z_to_x(z)
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+print("decode alone, %d x B=%d: %.2f ms" % (T, B, min(ts) * 1e3))

@@ -21,7 +21,7 @@ for comparison: 32.0k / 32.6k / 20.3k / 45.2k):
 |---|---|---|---|---|
 '''+"\n".join(rows)+'''
 
-The headline measured 33.7k - 35.5k across the boxes of the round with the same build (this set comes from the fastest one; config 4\nmeasured 69.4 - 76.6 ms) (the guide's rule 24: devices differ
+The headline measured 33.7k - 35.5k across the boxes of the round with the same build (this set comes from a middling one; config 4\nmeasured 69.4 - 76.6 ms) (the guide's rule 24: devices differ
 by several percent), which is why every change above is quoted as a same-box A/B: phase form +6 % (34.3k vs 32.3k),
 instruction trims +2.1 % (34.87k vs 34.15k), config 4's ragged-tile statistics +15 % (53.8k vs 46.9k) and 32-cout tiles +4 % (55.0k vs 52.8k).  Per kernel
 (`profiles/r03_serial_kernel_stats.csv` vs `r02_serial_kernel_stats.csv`, 10 single-stream rollouts): 3x3 class {:.0f} -> {:.0f} ms

@@ -157,6 +157,12 @@ int lns_encode(lns_engine* e, const float* x, int B, float* z,
 /* ConditionalSimpleAutoencoder.encode(x, param) (cfg.cond_encoder = 1): param [B] device, one value per sample. */
 int lns_encode_cond(lns_engine* e, const float* x, const float* param, int B, float* z,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* encode(x * scale + shift) with the affine map applied in the first convolution's prologue (device table
+ * scale_shift [B][in_channels][2]): the dataset normalisation (u - mean) / (std + eps) of the reference's encode_dataset
+ * (dataset/ns2d_fno_stage2_simpleae.py:78-93, dataset/Stage2_SW.py:74-105, dataset/twophase_flow_stage2.py:304-337)
+ * without a normalised copy of the frames.  param: NULL, or [B] for a conditional encoder. */
+int lns_encode_affine(lns_engine* e, const float* x, const float* scale_shift, const float* param, int B, float* z,
+                      void* workspace, size_t workspace_bytes, void* stream);
 /* SimpleAutoencoder.decode: z [B,latent_dim,h,w] -> y [B,Cin,Ly,Lx]. */
 int lns_decode(lns_engine* e, const float* z, int B, float* y,
                void* workspace, size_t workspace_bytes, void* stream);
@@ -224,6 +230,11 @@ int lns_timing_count(const lns_engine* e);
 int lns_timing_info(const lns_engine* e, int index, char* name, int name_capacity,
                     double* total_ms, int64_t* launches, double* flops, double* bytes);
 
+/* Build-time features of this library: "experimental" = compiled with -DLNS_EXPERIMENTAL (the measured-slower kernel
+ * forms behind op-level variants 15 / 16 / 18 / 19 exist; the shipped library does not carry them).  1 / 0; -1: unknown name.
+ * (No reference counterpart: the reference is pure Python.) */
+int lns_build_has(const char* feature);
+
 /* ---- kernel-level entry points (unit tests of the HIP kernels) ---------- */
 /* General fused convolution (the implicit-GEMM MFMA kernel):
  *   y = act_out( conv(act_in(x * scale + shift)) + bias + badd ) + residual
@@ -270,6 +281,20 @@ int lns_op_fourier_block(const float* x, int B, int Cin, int Cout, int H, int W,
                          const float* cond, const float* freq_w_host, const float* freq_b_host,
                          const float* lin_w_host, const float* lin_b_host, int activation, int residual,
                          float* y, void* stream);
+
+/* The same block as an object with DEVICE-RESIDENT weights: what a module instance (FourierBasicBlock.forward,
+ * modules/basics.py:574-583; CondFourierBasicBlock.forward, modules/fourier_cond.py:106-117) calls on every forward.
+ * create uploads the weights once (host pointers as above; freq_w_host == NULL: the unconditional block) onto HIP device
+ * `device`; forward only launches (asynchronous on `stream`; the scratch buffer grows when a larger shape arrives);
+ * cond must be given exactly when the block is conditional. */
+typedef struct lns_fourier_block lns_fourier_block;
+int lns_fourier_block_create(int Cin, int Cout, int m1, int m2, const float* w1_host, const float* w2_host,
+                             const float* conv_w_host, const float* conv_b_host, const float* freq_w_host,
+                             const float* freq_b_host, const float* lin_w_host, const float* lin_b_host, int activation,
+                             int residual, int device, lns_fourier_block** out);
+int lns_fourier_block_forward(lns_fourier_block* h, const float* x, const float* cond, int B, int H, int W, float* y,
+                              void* stream);
+void lns_fourier_block_destroy(lns_fourier_block* h);
 
 /* ---- "next row" (SURVEY 8f-2): the step right after the path -------------------------------------------------
  * Fused denormalise + relative-L2 metric of a decoded rollout against the ground truth, one pass over both tensors:

@@ -61,11 +61,12 @@ class LnsConfig(ctypes.Structure):
 SYMBOLS = [
     "lns_create_error", "lns_create", "lns_destroy", "lns_last_error", "lns_num_params",
     "lns_param_info", "lns_set_weight", "lns_finalize_weights", "lns_latent_shape", "lns_prepare",
-    "lns_encode", "lns_encode_cond", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite", "lns_set_option",
+    "lns_encode", "lns_encode_cond", "lns_encode_affine", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite", "lns_set_option",
     "lns_train_workspace_bytes", "lns_train_forward", "lns_train_backward",
     "lns_trace_enable", "lns_trace_count", "lns_trace_info", "lns_trace_copy",
-    "lns_timing_enable", "lns_timing_count", "lns_timing_info",
-    "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block", "lns_metric_rel_l2", "lns_metric_rel_l2_ch",
+    "lns_timing_enable", "lns_timing_count", "lns_timing_info", "lns_build_has",
+    "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block",
+    "lns_fourier_block_create", "lns_fourier_block_forward", "lns_fourier_block_destroy", "lns_metric_rel_l2", "lns_metric_rel_l2_ch",
 ]
 
 _lib = None
@@ -112,6 +113,7 @@ def lib():
     L.lns_decode.argtypes = [vp, vp, i, vp, vp, c.c_size_t, vp]
     if hasattr(L, "lns_encode_cond"):
         L.lns_encode_cond.argtypes = [vp, vp, vp, i, vp, vp, c.c_size_t, vp]
+    L.lns_encode_affine.argtypes = [vp, vp, vp, vp, i, vp, vp, c.c_size_t, vp]
     L.lns_propagate.argtypes = [vp, vp, vp, i, i, i, vp, vp, c.c_size_t, vp]
     L.lns_rollout.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, c.c_size_t, vp]
     L.lns_rollout_latent.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, c.c_size_t, vp]
@@ -123,6 +125,7 @@ def lib():
         L.lns_train_workspace_bytes.argtypes = [vp, i, i, i, i, c.POINTER(c.c_size_t)]
         L.lns_train_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, vp, c.c_size_t, vp]
         L.lns_train_backward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, c.c_size_t, vp]
+    L.lns_build_has.argtypes = [c.c_char_p]
     L.lns_trace_enable.argtypes = [vp, i]
     L.lns_trace_count.argtypes = [vp]
     L.lns_trace_info.argtypes = [vp, i, c.c_char_p, i, i64p]
@@ -137,6 +140,10 @@ def lib():
     L.lns_op_attention.argtypes = [vp, i, i, i, i, c.c_float, vp, vp]
     L.lns_op_fa_sandwich.argtypes = [vp, vp, vp, i, i, i, i, i, c.c_float, i, vp, vp]
     L.lns_op_fourier_block.argtypes = [vp, i, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp]
+    L.lns_fourier_block_create.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, c.POINTER(vp)]
+    L.lns_fourier_block_forward.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    L.lns_fourier_block_destroy.argtypes = [vp]
+    L.lns_fourier_block_destroy.restype = None
     L.lns_metric_rel_l2.argtypes = [vp, vp, i, i, i, i, c.c_float, c.c_float, c.c_float, vp, vp, vp, vp]
     L.lns_metric_rel_l2.restype = i
     L.lns_metric_rel_l2_ch.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp, c.c_float, c.c_float, c.c_float, vp, vp, vp, vp]

@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <tuple>
 #include <stdexcept>
 #include <type_traits>
 
@@ -281,6 +284,10 @@ static const char* kClsName[CLS_COUNT] = {"conv3x3_mfma", "conv1x1_mfma", "gn_st
                                           "fa_pool", "fa_reducer", "fa_lrk", "fa_sandwich", "cond_embed",
                                           "spectral", "misc"};
 
+// emit_conv: the geometry picked a kernel without the GELU prologue (input without a bound, patch too large for the
+// f16x2 tile, a tuning knob): the planner falls back to a materialised activation (emit_apply)
+struct NoGeluPrologue : std::runtime_error { using std::runtime_error::runtime_error; };
+
 struct Planner {
     lns_engine* e;
     Plan* plan;
@@ -448,7 +455,9 @@ struct Planner {
                 // foldable into the consumer's prologue: few tiles, one group or power-of-two groups within a wave
                 const int cg = x.C / groups;
                 static const int fold_tiles = getenv("LNS_GN_FOLD_TILES") ? atoi(getenv("LNS_GN_FOLD_TILES")) : 2;
-                const bool foldable = !no_fold && (exact || ragged1) && tiles <= fold_tiles && x.C <= 512 &&
+                // (a per-sample channel multiplier is applied by stage_ss_from_partials in its one-group branch only:
+                //  with several groups the finalize kernel, which handles premul for any grouping, runs instead)
+                const bool foldable = !no_fold && (exact || ragged1) && tiles <= fold_tiles && x.C <= 512 && (!premul || groups == 1) &&
                                       (groups == 1 || (cg <= 64 && (cg & (cg - 1)) == 0));
                 const int li = (int)lazy_ops.size();
                 lazy_done.push_back(0); lazy_folded.push_back(0);
@@ -503,8 +512,9 @@ struct Planner {
                            pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok))
             throw std::runtime_error("no conv tiling for " + name);
         if (up2 && g.variant != CV_F64) throw std::runtime_error("phase form needs the f16x2 64-cout tiles: " + name);
+        // (thrown before anything is allocated or emitted: a caller may catch it and materialise the activation instead)
         if (in.act == ACT_GELU && ((g.variant != CV_F64 && g.variant != CV_F32) || up2 || fuse_pack >= 0))
-            throw std::runtime_error("GELU prologue is only built into the f16x2 3x3 kernel: " + name);
+            throw NoGeluPrologue("GELU prologue is only built into the f16x2 3x3 kernel: " + name);
         if (up2) { g.Hout = 2 * in.H; g.Wout = 2 * in.W; }
         const ConvVariantInfo vi = conv_variant_info(g.variant);
         const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
@@ -975,9 +985,16 @@ struct Planner {
         static const bool no_gelu_pro = getenv("LNS_NO_GELU_PROLOGUE") != nullptr || getenv("LNS_CONV_FP32_MFMA") != nullptr;   // (strict-fp32 runs have no split-operand kernels)
         const ConvPack& cpk = e->packs[l.c_conv];
         TRef x1;
+        bool fused_gelu = false;
         if (!no_gelu_pro && cpk.has_wb && cpk.f16 && cpk.cout > 32) {
-            h2.act = ACT_GELU;
-            x1 = conv_same3(h2, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2", false);
+            // the pack is eligible; whether the GEOMETRY picks the f16x2 kernel is only known inside emit_conv
+            TRef h2g = h2; h2g.owned = false; h2g.ss_owned = false; h2g.act = ACT_GELU;
+            try {
+                x1 = conv_same3(h2g, l.c_conv, 1, l.mode_y, l.mode_x, ACT_NONE, &x, 0, q + ".cond_conv1.2", false);
+                fused_gelu = true;
+            } catch (const NoGeluPrologue&) {}
+        }
+        if (fused_gelu) {
             free_t(h2);
         } else {
             TRef h3 = emit_apply(h2, ACT_GELU, q + ".cond_conv1.1");
@@ -1255,8 +1272,14 @@ static int get_plan(lns_engine* e, PlanKind kind, int B, int H, int W, Plan** ou
             if (c.cond_encoder)   // CondEncoder.forward: cond_emb = embed(fourier_embedding(param, E))  (autoencoder2d_nonsquared.py:128)
                 pl.emit_cond_base(std::string(c.ae_prefix) + "encoder.embed", "0", "2", c.cond_emb_channels, c.encoder_channels[0],
                                   ACT_SWISH, pl.arena.alloc((size_t)B * c.cond_emb_channels * 4));
-            pl.lower_sequence(e->enc, ext_tensor(EX_IN, c.in_channels, c.Ly, c.Lx),
-                              ext_tensor(EX_OUT, e->lat_C, e->lat_H, e->lat_W));
+            TRef xin = ext_tensor(EX_IN, c.in_channels, c.Ly, c.Lx);
+            // lns_encode_affine (plan key H = 1): the caller's per-(sample, channel) (scale, shift) table is the pending
+            // prologue of the input, consumed by the encoder's first convolution (no normalised copy of the frames)
+            if (H == 1) {
+                if (e->enc[0].type != LT_CONV) throw std::runtime_error("encoder does not start with a convolution");
+                xin.ss = tag(SP_EXT0 + EX_SS, 0);
+            }
+            pl.lower_sequence(e->enc, xin, ext_tensor(EX_OUT, e->lat_C, e->lat_H, e->lat_W));
         } else if (kind == PK_DEC) {
             if (e->dec.empty()) throw std::runtime_error("engine has no autoencoder");
             pl.lower_sequence(e->dec, ext_tensor(EX_IN, e->lat_C, e->lat_H, e->lat_W),
@@ -1603,9 +1626,10 @@ using namespace lns;
 // launches must target the device that holds the packed weights, whatever the caller's current device is
 struct DeviceGuard {
     int prev = -1; bool switched = false;
-    explicit DeviceGuard(const lns_engine* e) {
-        if (e->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != e->device)
-            switched = hipSetDevice(e->device) == hipSuccess;
+    explicit DeviceGuard(const lns_engine* e) : DeviceGuard(e->device) {}
+    explicit DeviceGuard(int device) {
+        if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device)
+            switched = hipSetDevice(device) == hipSuccess;
     }
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
@@ -1735,7 +1759,8 @@ static int check_ws(lns_engine* e, const WsLayout& L, void* ws, size_t bytes) {
     return LNS_OK;
 }
 
-static int encode_impl(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream);
+static int encode_impl(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream,
+                       const float* ss = nullptr);
 
 // every top-level entry point: forget what the previous call ran (lns_check_finite looks at the LAST call only)
 static void begin_run(lns_engine* e, const void* ws, int B) {
@@ -1762,24 +1787,33 @@ int lns_encode_cond(lns_engine* e, const float* x, const float* param, int B, fl
     return encode_impl(e, x, param, B, z, ws, ws_bytes, stream);
 }
 
-static int encode_impl(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream) {
+static int encode_impl(lns_engine* e, const float* x, const float* param, int B, float* z, void* ws, size_t ws_bytes, void* stream,
+                       const float* ss) {
     if (!e || !x || !z || B <= 0) return LNS_EINVAL;
     if (int brc = check_batch(e, B)) return brc;
     DeviceGuard dg(e);
     WsLayout L; int rc;
     if ((rc = ws_layout(e, B, &L)) || (rc = check_ws(e, L, ws, ws_bytes))) return rc;
     Plan* p;
-    if ((rc = get_plan(e, PK_ENC, B, 0, 0, &p))) return rc;
+    if ((rc = get_plan(e, PK_ENC, B, ss ? 1 : 0, 0, &p))) return rc;
     const lns_config& c = e->cfg;
     ExtT ext[EX_COUNT];
     ext[EX_IN] = {x, (long)c.in_channels * c.Ly * c.Lx};
     ext[EX_OUT] = {z, (long)e->lat_C * e->lat_H * e->lat_W};
     ext[EX_PARAM] = {param, 1};
+    ext[EX_SS] = {ss, (long)c.in_channels * 2};
     Runner r(e, static_cast<hipStream_t>(stream));
     begin_run(e, ws, B);
     if ((rc = arm_sticky(e, r.stream))) return rc;
     if ((rc = r.run(*p, ext, static_cast<char*>(ws) + L.arena_off))) return rc;
     return r.finish();
+}
+
+int lns_encode_affine(lns_engine* e, const float* x, const float* scale_shift, const float* param, int B, float* z, void* ws,
+                      size_t ws_bytes, void* stream) {
+    if (!e || !scale_shift) { if (e) e->err = "lns_encode_affine needs the [B][C][2] (scale, shift) table"; return LNS_EINVAL; }
+    if ((e->cfg.cond_encoder != 0) != (param != nullptr)) { e->err = "param must be given exactly for a conditional encoder"; return LNS_EINVAL; }
+    return encode_impl(e, x, param, B, z, ws, ws_bytes, stream, scale_shift);
 }
 
 int lns_decode(lns_engine* e, const float* z, int B, float* y, void* ws, size_t ws_bytes, void* stream) {
@@ -2058,6 +2092,16 @@ int lns_timing_info(const lns_engine* e, int i, char* name, int cap, double* ms,
 }
 
 // ---- kernel-level entry points (tests) ------------------------------------------
+int lns_build_has(const char* feature) {
+    if (!feature) return -1;
+    if (!strcmp(feature, "experimental")) return build_has_experimental() ? 1 : 0;
+#ifdef LNS_DIAG
+    if (!strcmp(feature, "diag")) return 1;
+#else
+    if (!strcmp(feature, "diag")) return 0;
+#endif
+    return -1;
+}
 static thread_local std::string g_op_error;
 #define OPCHK(call)                                                                                   \
     do { hipError_t err__ = (call);                                                                   \
@@ -2438,6 +2482,106 @@ int lns_op_fourier_block(const float* x, int B, int Cin, int Cout, int H, int W,
     OPCHK(launch_fourier_combine(fc, s));
     OPCHK(hipStreamSynchronize(s));
     (void)hipFree(d);
+    return LNS_OK;
+}
+
+// ---- Fourier block with device-resident weights (the module objects of lns_amd.modules.fourier_cond) -----------------
+// lns_op_fourier_block uploads every weight on every call (a unit-test entry point); a module that is called repeatedly
+// keeps them on the device: create once per (weights, device), forward launches only.
+struct lns_fourier_block {
+    int Cin = 0, Cout = 0, m1 = 0, m2 = 0, conditional = 0, activation = ACT_GELU, residual = 1, device = 0;
+    std::vector<float> conv_w, conv_b;      // host copies: the 1x1 convolution's launch is prepared per (B, H, W)
+    float* dwt = nullptr;                    // [w1 | w2 | freq_w | freq_b | lin_w | lin_b]
+    size_t woff[6] = {0, 0, 0, 0, 0, 0};
+    float* scratch = nullptr; size_t scratch_floats = 0;
+    OpConv oc; bool oc_ready = false; int oc_B = 0, oc_H = 0, oc_W = 0; const float* oc_x = nullptr; float* oc_y = nullptr;
+};
+
+int lns_fourier_block_create(int Cin, int Cout, int m1, int m2, const float* w1_host, const float* w2_host,
+                             const float* conv_w_host, const float* conv_b_host, const float* freq_w_host,
+                             const float* freq_b_host, const float* lin_w_host, const float* lin_b_host, int activation,
+                             int residual, int device, lns_fourier_block** out) {
+    if (!out || !w1_host || !w2_host || !conv_w_host || Cin <= 0 || Cout <= 0 || m1 <= 0 || m2 <= 0) return LNS_EINVAL;
+    const bool cond = freq_w_host != nullptr;
+    if (cond && (!freq_b_host || !lin_w_host || !lin_b_host)) return LNS_EINVAL;
+    if (residual && Cin != Cout) return LNS_EINVAL;
+    if (activation < ACT_SWISH || activation > ACT_SIGMOID) return LNS_EINVAL;
+    DeviceGuard guard(device);
+    OPCHK(init_kernels());
+    std::unique_ptr<lns_fourier_block> h(new lns_fourier_block);
+    h->Cin = Cin; h->Cout = Cout; h->m1 = m1; h->m2 = m2; h->conditional = cond; h->activation = activation;
+    h->residual = residual; h->device = device;
+    h->conv_w.assign(conv_w_host, conv_w_host + (size_t)Cout * Cin);
+    if (conv_b_host) h->conv_b.assign(conv_b_host, conv_b_host + Cout);
+    const size_t nw = (size_t)Cin * Cout * m1 * m2 * 2, nf = (size_t)4 * m1 * m2;
+    const size_t sz[6] = {nw, nw, cond ? (size_t)Cin * nf : 0, cond ? nf : 0, cond ? (size_t)Cout * Cin : 0, cond ? (size_t)Cout : 0};
+    const float* src[6] = {w1_host, w2_host, freq_w_host, freq_b_host, lin_w_host, lin_b_host};
+    size_t tot = 0;
+    for (int i = 0; i < 6; ++i) { h->woff[i] = tot; tot += (sz[i] + 63) / 64 * 64; }
+    OPCHK(hipMalloc(reinterpret_cast<void**>(&h->dwt), std::max<size_t>(tot, 64) * 4));
+    for (int i = 0; i < 6; ++i)
+        if (sz[i]) OPCHK(hipMemcpy(h->dwt + h->woff[i], src[i], sz[i] * 4, hipMemcpyHostToDevice));
+    *out = h.release();
+    return LNS_OK;
+}
+
+void lns_fourier_block_destroy(lns_fourier_block* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    h->oc.release();
+    (void)hipFree(h->dwt);
+    (void)hipFree(h->scratch);
+    delete h;
+}
+
+int lns_fourier_block_forward(lns_fourier_block* h, const float* x, const float* cond, int B, int H, int W, float* y, void* stream) {
+    if (!h || !x || !y || B <= 0 || 2 * h->m1 > H || h->m2 > W / 2 + 1) return LNS_EINVAL;
+    if ((cond != nullptr) != (h->conditional != 0)) return LNS_EINVAL;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Cin = h->Cin, Cout = h->Cout, m1 = h->m1, m2 = h->m2;
+    const size_t nf = (size_t)4 * m1 * m2;
+    // scratch: [emb | e | t1 | xf | of | x1 | x2]; grown when a larger shape arrives (the only allocation after create)
+    const size_t sz[7] = {(size_t)B * nf, (size_t)B * Cout, (size_t)B * std::max(Cin, Cout) * H * m2 * 2, (size_t)B * Cin * 2 * m1 * m2 * 2,
+                          (size_t)B * Cout * 2 * m1 * m2 * 2, (size_t)B * Cout * H * W, (size_t)B * Cout * H * W};
+    size_t off[7], tot = 0;
+    for (int i = 0; i < 7; ++i) { off[i] = tot; tot += (sz[i] + 63) / 64 * 64; }
+    if (tot > h->scratch_floats) {
+        OPCHK(hipStreamSynchronize(s));
+        (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_floats = 0;
+        h->oc.release(); h->oc_ready = false;                     // (its output pointer lived in the old scratch)
+        OPCHK(hipMalloc(reinterpret_cast<void**>(&h->scratch), tot * 4));
+        h->scratch_floats = tot;
+    }
+    float* d = h->scratch;
+    if (cond) {
+        VecLinearArgs fl = {cond, h->dwt + h->woff[2], h->dwt + h->woff[3], d + off[0], B, Cin, (int)nf, 1, (int)nf};
+        OPCHK(launch_vec_linear(fl, s));
+        VecLinearArgs ll = {cond, h->dwt + h->woff[4], h->dwt + h->woff[5], d + off[1], B, Cin, Cout, Cin, 1};
+        OPCHK(launch_vec_linear(ll, s));
+    }
+    SpectralArgs sp;
+    memset(&sp, 0, sizeof sp);
+    sp.x = x; sp.x_bs = (long)Cin * H * W; sp.B = B; sp.Cin = Cin; sp.Cout = Cout; sp.H = H; sp.W = W; sp.m1 = m1; sp.m2 = m2;
+    sp.w1 = h->dwt + h->woff[0]; sp.w2 = h->dwt + h->woff[1]; sp.emb = cond ? d + off[0] : nullptr;
+    sp.t1 = d + off[2]; sp.xf = d + off[3]; sp.of = d + off[4]; sp.y = d + off[5];
+    OPCHK(launch_spectral(sp, s));
+    if (!h->oc_ready || h->oc_B != B || h->oc_H != H || h->oc_W != W) {
+        OPCHK(hipStreamSynchronize(s));
+        h->oc.release(); h->oc_ready = false;
+        const int rc = op_conv_prepare(h->oc, x, B, Cin, H, W, H, W, h->conv_w.data(), h->conv_b.empty() ? nullptr : h->conv_b.data(), Cout,
+                                       1, 1, 1, 0, 0, 0, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr, d + off[6], -1, s);
+        if (rc) { h->oc.release(); return rc; }
+        h->oc_ready = true; h->oc_B = B; h->oc_H = H; h->oc_W = W;
+    } else {          // same launch, new input: its per-sample maximum again (dynamic activation scale)
+        h->oc.a.x = x; h->oc.a.y = d + off[6];
+        OPCHK(hipMemsetAsync(h->oc.damax, 0, (size_t)B * LNS_AMAX_SUB * 4, s));
+        OPCHK(launch_amax(x, h->oc.a.x_bs, (long)Cin * H * W, B, h->oc.damax, s));
+    }
+    OPCHK(launch_conv(h->oc.variant, h->oc.a, s));
+    FourierCombineArgs fc = {d + off[5], d + off[6], cond ? d + off[1] : nullptr, h->residual ? x : nullptr, (long)Cin * H * W, y,
+                             (long)Cout * H * W, B, Cout, H * W, nullptr, h->activation};
+    OPCHK(launch_fourier_combine(fc, s));
     return LNS_OK;
 }
 

@@ -72,7 +72,7 @@ struct Layer {
 
 // ---- launch plan ---------------------------------------------------------------
 enum Space { SP_NULL = 0, SP_WS = 1, SP_WT = 2, SP_CT = 3, SP_EXT0 = 4 };   // ext slots: 4..11
-enum ExtSlot { EX_IN = 0, EX_OUT = 1, EX_PARAM = 2, EX_COUNT = 3 };
+enum ExtSlot { EX_IN = 0, EX_OUT = 1, EX_PARAM = 2, EX_SS = 3 /* [B][C][2] affine prologue of the input (lns_encode_affine) */, EX_COUNT = 4 };
 
 enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FARED2, OP_FALRK, OP_FALRK2, OP_FASAND, OP_CONDBASE, OP_CONDBLK,
               OP_APPLY, OP_SPECTRAL, OP_FCOMBINE, OP_VECLIN, OP_TRACE };

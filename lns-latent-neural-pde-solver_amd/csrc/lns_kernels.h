@@ -289,6 +289,7 @@ hipError_t launch_metric_rel_l2_ch(const float* yhat, const float* y, int B, int
 hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax, hipStream_t s);
 hipError_t launch_amax_sticky(const unsigned* amax, int n, unsigned* flag, hipStream_t s);
 
+bool build_has_experimental();   // compiled with -DLNS_EXPERIMENTAL: the measured-slower kernel forms (variants 15, 16, 18, 19) exist
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
 
 }  // namespace lns

@@ -2448,9 +2448,27 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Three kernel forms that were built, proven bit-identical to the shipped kernels and MEASURED SLOWER:
+// producer / consumer waves (conv3_pc.inc), the resident-patch upsampling conv (conv3_up2r.inc), the 8-wave small-launch
+// form (conv3_w8.inc).  They are kept as source with their parity tests but only compiled with -DLNS_EXPERIMENTAL
+// (make DIAGFLAGS=-DLNS_EXPERIMENTAL); the shipped library carries only kernels the planner uses.
+#ifdef LNS_EXPERIMENTAL
 #include "conv3_pc.inc"
 #include "conv3_up2r.inc"
 #include "conv3_w8.inc"
+bool build_has_experimental() { return true; }
+#else
+bool build_has_experimental() { return false; }
+size_t convpc_lds_bytes(const ConvArgs&, int) { return 0; }
+bool convpc_geom_fits(const ConvArgs&, int) { return false; }
+bool convpc_fits(const ConvArgs&, int) { return false; }
+hipError_t launch_conv_pc(int, const ConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
+bool convur_fits(const ConvArgs&) { return false; }
+size_t convur_lds_bytes(const ConvArgs&) { return 0; }
+hipError_t launch_conv_up2r(const ConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
+bool convw8_fits(const ConvArgs&) { return false; }
+hipError_t launch_conv_w8(const ConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
+#endif
 
 // ===========================================================================
 // Thin 1x1 projection (<= 4 output channels, e.g. the decoder's last 64 -> 3 conv): pure streaming, no matrix pipe.
@@ -4826,6 +4844,7 @@ hipError_t init_kernels() {
 #define LNS_SET_LDS(k)                                                                            \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
+#ifdef LNS_EXPERIMENTAL
     LNS_SET_LDS(conv3_w8_kernel<1>)
     LNS_SET_LDS(conv3_w8_kernel<2>)
     LNS_SET_LDS((conv3_up2r_kernel<true>))
@@ -4834,6 +4853,7 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv3_pc_kernel<1, 2>))
     LNS_SET_LDS((conv3_pc_kernel<2, 1>))
     LNS_SET_LDS((conv3_pc_kernel<2, 2>))
+#endif
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false, 4>))
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 3, false, 8>))
     LNS_SET_LDS((conv_mfma_kernel<2, 4, 2, 2, 1, true, 16>))

@@ -9,7 +9,11 @@ attribute names and state_dict keys/shapes
 but hold NO arithmetic: the parameter tree is generated from the engine's
 parameter table (the single definition of the architecture lives in
 csrc/lns_model.cpp) and every call runs the HIP engine through the C ABI.
-They are inference-only (the reference wraps this path in torch.no_grad()).
+Gradients exist through ONE entry point, `LatentDynamics.forward(z_in, z_out[, param], loss_fn)` (the stage-2 training
+rollout), and only for the propagator's parameters.  Everything else is inference (the reference wraps this
+path in torch.no_grad()): autoencoder parameters are created with requires_grad=False (stage-1 training is out of scope),
+and `SimpleCNN.forward` / `SimpleAutoencoder.{encode,decode,forward}` raise LnsError when they are called with autograd
+enabled on something that requires grad -- instead of returning a tensor without grad_fn that only fails at backward().
 """
 import math
 import types
@@ -109,7 +113,17 @@ def _init_value(key, shape, sibling_weight_shape):
     return t.zero_()
 
 
-def _grow_tree(root, table, strip=""):
+def _no_backward(what, *tensors, params=()):
+    """Called at the top of an inference-only forward.  With autograd enabled and an input (or a parameter) that requires
+    grad the caller expects a differentiable result; there is no backward for this path, so say so here."""
+    if not torch.is_grad_enabled():
+        return
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors) or any(p.requires_grad for p in params):
+        raise LnsError("%s has no backward: gradients exist only through LatentDynamics.forward(z_in, z_out[, param], "
+                       "loss_fn); call it under torch.no_grad() (or on tensors / parameters with requires_grad=False)" % what)
+
+
+def _grow_tree(root, table, strip="", requires_grad=True):
     shapes = {k: s for k, s, _ in table}
     for key, shape, is_buffer in table:
         assert key.startswith(strip), (key, strip)
@@ -124,7 +138,7 @@ def _grow_tree(root, table, strip=""):
         if is_buffer:
             node.register_buffer(parts[-1], val)
         else:
-            node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=True))     # as the reference's nn.Modules
+            node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=requires_grad))
 
 
 class _Hosted(_TreeWatch):
@@ -184,18 +198,20 @@ class SimpleAutoencoder(_Hosted):
         if _owner is None:
             cfg = _engine.make_config(args, ae_kind=self._ae_kind, prop_kind=LNS_PROP_NONE)
             self._init_host(cfg=cfg)
-            _grow_tree(self, self._eng.params)
+            _grow_tree(self, self._eng.params, requires_grad=False)      # no backward through the autoencoder (module docstring)
         else:
             self._init_host(owner=_owner, prefix=_prefix)
-            _grow_tree(self, [p for p in _owner._eng.params if p[0].startswith(_prefix)], strip=_prefix)
+            _grow_tree(self, [p for p in _owner._eng.params if p[0].startswith(_prefix)], strip=_prefix, requires_grad=False)
 
-    @torch.no_grad()
     def encode(self, x):
-        return self._engine(x).encode(x)
+        _no_backward("SimpleAutoencoder.encode", x, params=self.parameters())
+        with torch.no_grad():
+            return self._engine(x).encode(x)
 
-    @torch.no_grad()
     def decode(self, z):
-        return self._engine(z).decode(z)
+        _no_backward("SimpleAutoencoder.decode", z, params=self.parameters())
+        with torch.no_grad():
+            return self._engine(z).decode(z)
 
     def forward(self, x):
         return self.decode(self.encode(x))
@@ -227,9 +243,10 @@ class ConditionalSimpleAutoencoder(SimpleAutoencoder):
             args.cond_encoder = True
         super().__init__(args)
 
-    @torch.no_grad()
     def encode(self, x, param):
-        return self._engine(x).encode(x, param)
+        _no_backward("ConditionalSimpleAutoencoder.encode", x, params=self.parameters())
+        with torch.no_grad():
+            return self._engine(x).encode(x, param)
 
     def forward(self, x, param):
         return self.decode(self.encode(x, param))
@@ -260,9 +277,10 @@ class SimpleCNN(_Hosted):
             self._init_host(owner=_owner, prefix=_prefix)
             _grow_tree(self, [p for p in _owner._eng.params if p[0].startswith(_prefix)], strip=_prefix)
 
-    @torch.no_grad()
     def forward(self, z, param=None):
-        return self._engine(z).propagate(z, param)
+        _no_backward("SimpleCNN.forward", z, params=self.parameters())
+        with torch.no_grad():
+            return self._engine(z).propagate(z, param)
 
 
 class SimpleCNNHalfPeriodic(SimpleCNN):       # train_stage2_SW.py:56-87 (periodic_direction='x')
@@ -282,9 +300,10 @@ class SimpleCNNConditional(SimpleCNN):        # train_stage2_twophase_conditiona
                          _cond_emb_dim=cond_emb_dim)
         self.cond_emb_dim = cond_emb_dim
 
-    @torch.no_grad()
     def forward(self, z, param):
-        return self._engine(z).propagate(z, param)
+        _no_backward("SimpleCNN.forward", z, params=self.parameters())
+        with torch.no_grad():
+            return self._engine(z).propagate(z, param)
 
 
 # ---------------------------------------------------------------------------

@@ -219,13 +219,26 @@ class Engine:
             raise LnsError("fp32 tensors expected, got %s" % t.dtype)
         return t.contiguous()
 
-    def encode(self, x, param=None):
+    def encode(self, x, param=None, scale_shift=None):
+        """scale_shift [B, in_channels, 2] (device): encode(x * scale + shift) with the affine map applied in the first
+        convolution's prologue (lns_encode_affine; the dataset normalisation of encode_dataset)."""
         import torch
         x = self._dev(x)
         B = x.shape[0]
         C, H, W = self.latent_shape()
         z = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         ws = self._workspace(B, x.device)
+        if scale_shift is not None:
+            ss = self._dev(scale_shift)
+            if tuple(ss.shape) != (B, self.cfg.in_channels, 2) or ss.device != x.device:
+                raise LnsError("scale_shift must be [B, in_channels, 2] on the input's device")
+            if bool(self.cfg.cond_encoder) != (param is not None):
+                raise LnsError("param must be given exactly for a conditional encoder")
+            p = self._param(param, x) if param is not None else None
+            self._check(self._L.lns_encode_affine(self._h, x.data_ptr(), ss.data_ptr(), p.data_ptr() if p is not None else None,
+                                                  B, z.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(x)),
+                        "lns_encode_affine")
+            return z
         if self.cfg.cond_encoder:
             if param is None:
                 raise LnsError("this autoencoder's encoder is conditional: encode(x, param)")

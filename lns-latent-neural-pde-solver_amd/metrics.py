@@ -103,19 +103,23 @@ def encode_dataset(autoencoder, frames, chunk=32, mean=0.0, std=1.0, eps=1e-8, o
     C = frames.shape[1]
 
     def stat(v):
-        if isinstance(v, (int, float)):
-            return float(v)
-        t = torch.as_tensor([float(e) for e in v], dtype=torch.float32, device=dev)
-        if t.numel() != C:
+        v = [float(v)] * C if isinstance(v, (int, float)) else [float(e) for e in v]
+        if len(v) != C:
             raise ValueError("per-channel statistics need %d entries" % C)
-        return t.reshape(1, C, 1, 1)
+        return v
+    # (u - mean) / (std + eps) = u * scale + shift, in fp64 on the host: 2 C numbers.  The map is applied inside the
+    # encoder's first convolution (its per-(sample, channel) scale / shift prologue, lns_encode_affine): no normalised copy
+    # of the frames is ever written, and no tensor arithmetic runs outside the HIP kernels.
     m, sd = stat(mean), stat(std)
+    table = torch.tensor([[1.0 / (s_ + eps), -m_ / (s_ + eps)] for m_, s_ in zip(m, sd)], dtype=torch.float64)
+    table = table.to(torch.float32).to(dev)
     if param is not None:
         param = torch.as_tensor(param)
     outs = []
     for s in range(0, frames.shape[0], chunk):
         u = frames[s:s + chunk].to(dev, dtype=torch.float32)
-        u = (u - m) / (sd + eps)
-        z = autoencoder.encode(u) if param is None else autoencoder.encode(u, param[s:s + chunk].to(dev))
+        ss = table.unsqueeze(0).expand(u.shape[0], C, 2).contiguous()
+        eng = autoencoder._engine(u)
+        z = eng.encode(u, None if param is None else param[s:s + chunk].to(dev), scale_shift=ss)
         outs.append(z.to(out_device))
     return torch.cat(outs, 0)

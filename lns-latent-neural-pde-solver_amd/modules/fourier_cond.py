@@ -50,6 +50,44 @@ class _FourierBase(nn.Module):
             self.cond_emb.weight = nn.Parameter(torch.empty(planes, in_planes).uniform_(-b, b), requires_grad=False)
             self.cond_emb.bias = nn.Parameter(torch.empty(planes).uniform_(-b, b), requires_grad=False)
 
+    def _weights(self):
+        ws = [self.fourier.weights1, self.fourier.weights2, self.conv.weight, self.conv.bias]
+        if hasattr(self.fourier, "cond_emb"):
+            ws += [self.fourier.cond_emb.weights, self.fourier.cond_emb.bias, self.cond_emb.weight, self.cond_emb.bias]
+        return ws
+
+    def _handle_for(self, device):
+        """The engine-side block object (weights resident on `device`).  Rebuilt when a parameter tensor was replaced or
+        written in place (load_state_dict, an optimiser step, .to()) or the device changed; otherwise a forward uploads
+        nothing."""
+        ws = self._weights()
+        sig = (device.index,) + tuple((id(w), w.data_ptr(), w._version) for w in ws)
+        if getattr(self, "_h_sig", None) == sig:
+            return self._h
+        self._drop_handle()
+        keep = [_host(w) for w in ws]
+        ptr = [k[1] for k in keep] + [None] * (8 - len(keep))
+        h = ctypes.c_void_p()
+        rc = _lib.lib().lns_fourier_block_create(self.in_planes, self.planes, self.modes[0], self.modes[1], ptr[0], ptr[1],
+                                                 ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], self._act,
+                                                 int(self.residual), device.index, ctypes.byref(h))
+        if rc != 0:
+            raise LnsError("lns_fourier_block_create failed (%d)" % rc)
+        self._h, self._h_sig = h, sig
+        return h
+
+    def _drop_handle(self):
+        h = getattr(self, "_h", None)
+        if h is not None:
+            _lib.lib().lns_fourier_block_destroy(h)
+        self._h, self._h_sig = None, None
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:  # noqa: BLE001 (interpreter shutdown)
+            pass
+
     @torch.no_grad()
     def _run(self, x, cond):
         if not x.is_cuda or x.dtype != torch.float32:
@@ -58,26 +96,20 @@ class _FourierBase(nn.Module):
         B, C, H, W = x.shape
         if C != self.in_planes:
             raise LnsError("expected %d input channels, got %d" % (self.in_planes, C))
+        if (cond is not None) != hasattr(self.fourier, "cond_emb"):
+            raise LnsError("cond_emb must be given exactly for the conditional block")
         y = torch.empty((B, self.planes, H, W), dtype=torch.float32, device=x.device)
-        keep = [_host(self.fourier.weights1), _host(self.fourier.weights2), _host(self.conv.weight), _host(self.conv.bias)]
-        args = [k[1] for k in keep]
         cptr = None
-        extra = [None, None, None, None]
         if cond is not None:
-            cond = cond.to(torch.float32).contiguous()
+            cond = cond.to(device=x.device, dtype=torch.float32).contiguous()
             cptr = ctypes.c_void_p(cond.data_ptr())
-            k2 = [_host(self.fourier.cond_emb.weights), _host(self.fourier.cond_emb.bias), _host(self.cond_emb.weight),
-                  _host(self.cond_emb.bias)]
-            keep += k2
-            extra = [k[1] for k in k2]
         with torch.cuda.device(x.device):
-            rc = _lib.lib().lns_op_fourier_block(ctypes.c_void_p(x.data_ptr()), B, C, self.planes, H, W, self.modes[0],
-                                                 self.modes[1], args[0], args[1], args[2], args[3], cptr, extra[0],
-                                                 extra[1], extra[2], extra[3], self._act, int(self.residual),
-                                                 ctypes.c_void_p(y.data_ptr()),
-                                                 ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            h = self._handle_for(x.device)
+            rc = _lib.lib().lns_fourier_block_forward(h, ctypes.c_void_p(x.data_ptr()), cptr, B, H, W,
+                                                      ctypes.c_void_p(y.data_ptr()),
+                                                      ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
-            raise LnsError("lns_op_fourier_block failed (%d)" % rc)
+            raise LnsError("lns_fourier_block_forward failed (%d)" % rc)
         return y
 
 

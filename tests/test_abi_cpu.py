@@ -65,6 +65,25 @@ def test_dropin_state_dict_and_cpu_refusal():
     assert "no CPU fallback" in str(ei.value)
 
 
+def test_inference_only_forwards_refuse_autograd():
+    """gradients exist only through LatentDynamics.forward.  Autoencoder parameters are created with
+    requires_grad=False; SimpleCNN.forward / SimpleAutoencoder.encode raise a clear error when called with autograd enabled
+    on something that requires grad (before any device work: this runs without a GPU)."""
+    import torch
+    from lns_amd import config, dropin
+    from lns_amd._lib import LnsError
+    m = dropin.build_dynamics(config.preset("ns2d_mini"))
+    assert not any(p.requires_grad for p in m.vq_ae.parameters())
+    assert all(p.requires_grad for p in m.propagator.parameters())
+    z = torch.zeros(2, 4, 8, 8)
+    with pytest.raises(LnsError, match="no backward"):
+        m.propagator(z)
+    with pytest.raises(LnsError, match="no backward"):
+        m.vq_ae.encode(torch.zeros(2, 2, 32, 32, requires_grad=True))
+    with torch.no_grad(), pytest.raises(LnsError, match="no CPU fallback"):      # inference context: the usual device refusal
+        m.propagator(z)
+
+
 def test_dropin_sees_replaced_tensors():
     """the drop-in caches the flat (key, tensor) list of its parameter tree; anything that REPLACES tensor
     objects (load_state_dict(assign=True), `mod.w = nn.Parameter(...)`, `.to()` which rebinds buffers before a later

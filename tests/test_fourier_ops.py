@@ -60,6 +60,18 @@ def test_hip_fourier_blocks_match_reference(conditional):
     y = y.cpu().numpy()
     assert rel_l2(y, d[name + "_y"]) < 5e-6
     assert rel_l2(y, d[name + "_y_f64"]) < 5e-6
+    # the block object keeps its weights on the device: a second forward uploads nothing and gives the same bits, another
+    # batch size re-plans, and a weight written in place is seen (the handle is rebuilt from the parameters' versions)
+    cd = torch.from_numpy(cond).cuda()
+    run = (lambda xx, cc: blk(xx, cc)) if conditional else (lambda xx, cc: blk(xx))
+    h0 = blk._h.value
+    assert np.array_equal(run(xd, cd).cpu().numpy(), y) and blk._h.value == h0
+    assert np.array_equal(run(xd[:1].contiguous(), cd[:1].contiguous()).cpu().numpy(), y[:1])
+    assert np.array_equal(run(xd, cd).cpu().numpy(), y)
+    with torch.no_grad():
+        blk.conv.bias.add_(1.0)
+    y3 = run(xd, cd).cpu().numpy()
+    assert not np.array_equal(y3, y) and np.isfinite(y3).all()
 
 
 def _gen_cases():

@@ -12,11 +12,14 @@ and the MAX over ranks is taken.  For N > 1 trajectories are sharded over ranks 
 data-path collective) and the decoded shards are all-gathered over RCCL in step blocks, overlapped with the remaining
 rollout.  Rank 0 prints ONE JSON line.
 
-What the line carries besides the contract fields: `roofline` (dominant kernel class, HIP-event timed on the launch
-stream), `kernel_classes`, `check` (the first two trajectories are the golden fixture's inputs: their decoded fields
-are compared with the REAL reference's outputs), `strict_fp32` (the same workload with every contraction on the
-exact-fp32 MFMA instruction, child process), `cpu_baseline` (the oracle port timed on this host + its calibration
-against the real reference).
+What the line carries besides the contract fields: `roofline` (the dominant KERNEL -- the nine-tap f16x2 3x3 convolution --
+HIP-event timed on the launch stream, with the other kernel forms of its class, the executed matrix-pipe FLOP and the
+whole-path floors beside it; formulas in DESIGN.md section 6e), `kernel_classes`, `check` (the first two trajectories are
+the golden fixture's inputs: their decoded fields are compared with the REAL reference's outputs), `check_stable` (the same
+shape on the `stable` weight variant, gated at 1e-4 at EVERY stored step of the full horizon), `strict_fp32` (the same
+workload with every contraction on the exact-fp32 MFMA instruction, child process), `rccl_world1` (the RCCL path executed
+with ONE rank on the config-5 shard: `--force-dist`, child process), `cpu_baseline` (the oracle port timed on this host +
+its calibration against the real reference).
 """
 import argparse
 import json
@@ -37,6 +40,10 @@ SPLIT_EXEC_PER_ALGO = 3.0 * 10.0 / 9.0
 DTYPE = "f32 (f16x2 split operands on the fp16 MFMA pipe, fp32 accumulate; fp32 tensors in HBM)"
 
 # preset -> (metric label, workload label, golden fixture with the reference's outputs for the first two trajectories)
+# (preset, T) -> fixture of the REAL reference on the `stable` filler variant (non-expansive latent chain: 1e-4 gated at every
+# stored step of the full horizon, tools/make_golden.py)
+STABLE_FIXTURES = {("ns2d_128", 256): "ns2d_128_T256_stable", ("sw_96x192x5", 64): "sw_96x192x5_T64_stable",
+                   ("twophase_cond", 128): "twophase_cond_T128_stable"}
 WORKLOADS = {
     "ns2d_128": ("NS2d 128^2 3-ch", "NS2d 128x128 3-channel", {64: "ns2d_128", 256: "ns2d_128_T256"}),
     "sw_96x192x5": ("shallow-water 96x192 5-ch (autoencoder2d_nonsquared)", "Shallow-water 96x192 5-channel", {64: "sw_96x192x5_T64"}),
@@ -48,13 +55,13 @@ WORKLOADS = {
 }
 
 
-def build_model(preset, device):
+def build_model(preset, device, variant=None):
     import torch
     from lns_amd import config, dropin, filler
     args = config.preset(preset)
     model = dropin.build_dynamics(args)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = filler.synthetic_state_dict(shapes, 1)
+    sd = filler.synthetic_state_dict(shapes, 1, variant)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return args, model.to(device), sd
 
@@ -121,6 +128,112 @@ def traffic_from_profiles(kernel):
         return None
 
 
+def _pmc_busy(kernel_substr):
+    """MFMA-pipe busy fraction of a kernel from the newest committed counter pass (profiles/r*_pmc.json, tools/pmc_summary.py;
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE in its own run).  bench.py cannot run the profiler itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            for name, rec in d.get("kernels", {}).items():
+                if kernel_substr in name and "mfma_util" in rec:
+                    return {"mfma_busy": rec["mfma_util"], "effective_clock_ghz": rec.get("effective_clock_ghz"),
+                            "lds_array_busy": rec.get("lds_array_util"), "lds_bank_conflict_share": rec.get("lds_bank_conflict_share"),
+                            "source": os.path.basename(f), "kernel": name}
+        except Exception:
+            continue
+    return None
+
+
+def _total_traffic():
+    """HBM bytes of one single-stream rollout of the headline workload from the newest committed counter passes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            t = d.get("rollout_total")
+            if t:
+                hb = t.get("hbm_bytes", t.get("fetch_bytes_raw", 0.0) + t.get("write_bytes", 0.0))
+                return {"hbm_bytes": hb, "fetch_bytes_raw": t.get("fetch_bytes_raw"), "write_bytes": t.get("write_bytes"),
+                        "workload": t.get("workload", "NS2d 128x128x3, B=64, T=64, single-stream rollout (+ encode)"),
+                        "source": os.path.basename(f)}
+        except Exception:
+            continue
+    return None
+
+
+def roofline_record(forms, classes, ms_per_step, path_tflops):
+    """The `roofline` object.  DESIGN.md section 6e has the formulas; every number follows from the per-form timing records
+    of the engine (HIP events, single-stream pass) and reproduces from `rocprofv3 --kernel-trace --stats -- python bench.py
+    --serial` (profiles/r04_serial_kernel_stats.csv) through tools/roofline_from_stats.py."""
+    NINE = "conv3x3_mfma/f16x2 3x3 nine-tap"
+    entries = []
+    for name, v in sorted(forms.items(), key=lambda kv: -kv[1]["ms"]):
+        cls, form = name.split("/", 1)
+        sec = v["ms"] * 1e-3
+        f16 = form.startswith("f16x2") or form.startswith("bf16x3")
+        fp32 = form.startswith("fp32 MFMA")
+        peak_exec = F16_MFMA_PEAK_TFLOPS if f16 else (FP32_MFMA_PEAK_TFLOPS if fp32 else None)
+        e = {"class": cls, "form": form, "ms": round(v["ms"], 3), "launches": v["launches"],
+             "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
+             "algorithmic_tflops": round(v["flops"] / sec / 1e12, 2) if v["flops"] else None,
+             "executed_mfma_tflops": round(v["mfma_flops"] / sec / 1e12, 2) if v["mfma_flops"] else None,
+             "pipe": "fp16 MFMA (v_mfma_f32_32x32x16_f16)" if f16 else ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if fp32 else "none"),
+             # executed FLOP / the pipe's dense peak = the share of the launch time the matrix pipe would be busy at 2.4 GHz
+             "executed_frac_of_pipe_peak": round(v["mfma_flops"] / sec / 1e12 / peak_exec, 4) if (peak_exec and v["mfma_flops"]) else None,
+             "gbps": round(v["bytes"] / sec / 1e9, 1) if v["bytes"] else None}
+        entries.append(e)
+    k = forms.get(NINE)
+    rec = {"entries": entries}
+    if k:
+        sec = k["ms"] * 1e-3
+        ach = k["flops"] / sec / 1e12
+        peak = F16_MFMA_PEAK_TFLOPS / SPLIT_EXEC_PER_ALGO
+        pmc = _pmc_busy("conv3_bf16x3_kernel<1, 1, false, 2, 2, 9>")
+        td = traffic_from_profiles("conv3x3")
+        rec.update({
+            "kernel": "conv3_bf16x3_kernel<NT, NU, false, MT, SPL=2, NTAP=9> (the nine-tap f16x2 3x3 implicit GEMM: fp32 operands as 2 fp16 "
+                      "terms on v_mfma_f32_32x32x16_f16, fp32 accumulate) -- this KERNEL only: the four-tap phase form, the fused "
+                      "3x3 + 1x1 form and the fp32-MFMA 3x3 convs are separate entries",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "peak_basis": "algorithmic fp32 FLOP of the kernel's launches / their summed duration, against the dense fp16 MFMA peak "
+                          "%.1f / %.2f executed fp16 FLOP per algorithmic FLOP (3 products x 10 tap slots for 9 taps)" % (
+                              F16_MFMA_PEAK_TFLOPS, SPLIT_EXEC_PER_ALGO),
+            # the three useful products only (no tap padding): what a perfect kernel of this scheme would need
+            "useful_products_frac": 3.0 * ach / F16_MFMA_PEAK_TFLOPS,
+            # everything the launches issue (tap slot 10, channel / cout / pixel padding of ragged tiles): ~ MFMA busy x clock / 2.4 GHz
+            "executed_frac": k["mfma_flops"] / sec / 1e12 / F16_MFMA_PEAK_TFLOPS,
+            "mfma_busy_pmc": pmc,
+            "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": (td or {}).get("hbm_bytes_per_launch"), "traffic_detail": td,
+            "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
+            "algorithmic_flop_per_launch": k["flops"] / k["launches"],
+            "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
+            "mode": "single-stream diagnostic pass (python bench.py --serial reproduces it under rocprofv3)",
+        })
+    # whole path: what the matrix pipe and HBM would need at their peaks vs what one rollout takes
+    f16_exec = sum(v["mfma_flops"] for n, v in forms.items() if n.split("/", 1)[1].startswith(("f16x2", "bf16x3")))
+    f32_exec = sum(v["mfma_flops"] for n, v in forms.items() if n.split("/", 1)[1].startswith("fp32 MFMA"))
+    tt = _total_traffic()
+    wp = {"measured_ms_overlapped": ms_per_step, "measured_ms_serial_kernel_sum": sum(v["ms"] for v in classes.values()),
+          "executed_f16_mfma_tflop": f16_exec / 1e12, "executed_fp32_mfma_tflop": f32_exec / 1e12,
+          "mfma_floor_ms": (f16_exec / (F16_MFMA_PEAK_TFLOPS * 1e12) + f32_exec / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3,
+          "algorithmic_tflops": path_tflops,
+          "note": "mfma_floor_ms: executed matrix-pipe FLOP of every convolution / sandwich / attention launch at the dense "
+                  "peaks (2516.6 fp16, 157.3 fp32 TFLOP/s, 2.4 GHz; an MFMA-dense loop on random data holds 1.5-1.9 GHz: "
+                  "MI355X_MICROARCH.md DVFS give-back); hbm_floor_ms: counter bytes of one single-stream rollout / 6.3 TB/s "
+                  "(achievable HBM rate, same guide)"}
+    if tt:
+        wp["hbm_bytes_per_rollout"] = tt.get("hbm_bytes")
+        wp["hbm_floor_ms"] = tt.get("hbm_bytes", 0.0) / 6.3e12 * 1e3
+        wp["traffic_source"] = tt.get("source")
+        wp["traffic_workload"] = tt.get("workload")
+    rec["whole_path"] = wp
+    return rec
+
+
 def golden_check(preset, T, out2, fixture):
     """out2: decoded fields of the first two trajectories [2,T,C,H,W] (numpy).  Compared with the committed outputs of
     the REAL reference on the same inputs/weights (tests/golden/<fixture>.npz, tools/make_golden.py): sub-sampled
@@ -148,19 +261,36 @@ def golden_check(preset, T, out2, fixture):
     # further out, against the fp64 run, at most 2x the MAXIMUM over the fixture's ensemble of real-reference fp32 runs
     # at that step while that maximum is below 1e-2 (tests/test_gpu_parity.py, same rule; tools/make_golden.py `ens`)
     ens = g["ref_ens_err_sub"] if "ref_ens_err_sub" in g else None
+    stable = meta.get("filler_variant") == "stable"
     ok = True
+    outside = False
     for r in rows:
         n = r["reference_fp32_vs_fp64"]
         if n <= 3e-5:
             ok = ok and r["rel_l2_vs_reference_fp32"] < 1e-4
+        if stable:          # full-horizon fixture: the reference is reproducible at every step, so every step is gated
+            ok = ok and n <= 3e-5 and r["rel_l2_vs_reference_fp32"] < 1e-4 and r["rel_l2_vs_reference_fp64"] < 1e-4
         if ens is not None:
             i = meta["steps"].index(r["step"])
             emax = float(ens[:, i].max())
             r["reference_ensemble_max_vs_fp64"] = emax
             r["reference_ensemble_median_vs_fp64"] = float(np.median(ens[:, i]))
+            # inside the spread of the real reference's own fp32 runs, or beyond their maximum (still within the 2x gate)?
+            r["outside_reference_ensemble"] = bool(r["rel_l2_vs_reference_fp64"] > emax)
+            outside = outside or r["outside_reference_ensemble"]
             if emax <= 1e-2:
                 ok = ok and r["rel_l2_vs_reference_fp64"] <= max(2.0 * emax, 2e-5)
-    return {"fixture": fixture + ".npz", "trajectories": 2, "finite": bool(np.isfinite(out2).all()), "steps": rows,
+        elif n > 3e-5:
+            # no ensemble in the fixture: the single-run rule of round 2 (5x the reference's own fp32-vs-fp64 distance up
+            # to 64 steps, 10x beyond) rather than no gate at all
+            r["gate"] = "no ensemble arrays: %dx reference_fp32_vs_fp64" % (5 if r["step"] <= 64 else 10)
+            if n <= 1e-2:
+                ok = ok and r["rel_l2_vs_reference_fp64"] <= (5.0 if r["step"] <= 64 else 10.0) * n
+    return {"fixture": fixture + ".npz", "filler_variant": meta.get("filler_variant", "default"), "trajectories": 2,
+            "finite": bool(np.isfinite(out2).all()), "steps": rows, "outside_reference_ensemble": bool(outside),
+            "gate": ("1e-4 vs the reference's fp32 AND fp64 runs at every stored step (reference ensemble <= 3e-5 throughout)" if stable else
+                     "1e-4 vs the fp32 run where the reference is reproducible to 3e-5; vs the fp64 run at most 2x the maximum of "
+                     "the reference's own ten-member fp32 ensemble while that is below 1e-2"),
             "max_frame_norm_rel_dev_vs_reference_fp64": nerr, "pass": bool(ok and np.isfinite(out2).all())}
 
 
@@ -200,7 +330,8 @@ def plumbing_pass(a, rank, world, dist, dev):
     if a.gather_mode == "end":
         def rollout(x, out):
             rollout_latent(encode(x), T, out)
-        chunked = parallel.EndGatherRollout(rollout, (C, H, W), B, T, dev, gather=world > 1)
+        chunked = parallel.EndGatherRollout(rollout, (C, H, W), B, T, dev, gather=world > 1 or a.force_dist,
+                                            collective_at_world1=a.force_dist)
     else:
         chunked = parallel.ChunkedGatherRollout(encode, rollout_latent, (C, H, W), B, T, a.gather_chunk, dev, gather=world > 1)
     x = torch.full((B, C, H, W), float(rank), device=dev)
@@ -234,6 +365,12 @@ def main():
                     help="single-stream execution (no propagate/decode overlap): the mode the per-kernel roofline "
                          "pass uses; profile THIS mode to compare rocprofv3 averages with the roofline block")
     ap.add_argument("--plumbing-only", action="store_true", help="orchestration only, no compute (CPU tests of the launcher)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: init_process_group(nccl, world_size=1) in this process before any other GPU call and "
+                         "run the end-of-rollout all_gather_into_tensor on the shard anyway (RCCL executed on a one-GPU box; "
+                         "the gathered buffer must equal the shard bit for bit).  Not a scaling measurement")
+    ap.add_argument("--no-rccl-world1", action="store_true", help="skip the rccl_world1 sub-record (child process, --force-dist on the config-5 shard)")
+    ap.add_argument("--no-check-stable", action="store_true")
     ap.add_argument("--strict-fp32-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.batch is None:
@@ -253,10 +390,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = not (a.plumbing_only and a.dist_backend == "gloo" and not torch.cuda.is_available())
     dist = None
-    if world > 1:
+    force_dist = a.force_dist and world == 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if force_dist:          # one rank, no launcher: rendezvous with ourselves on a free local port
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            sk.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if on_gpu:
             dev_index = a.device if a.device is not None else local_rank
             torch.cuda.set_device(dev_index)
@@ -280,7 +426,7 @@ def main():
     B, T = a.batch, a.rollout
     label, wl, fixtures = WORKLOADS.get(a.preset, (a.preset, a.preset, {}))
     fixture = None if a.no_check else fixtures.get(T)
-    gather = world > 1 and not a.no_gather
+    gather = (world > 1 or force_dist) and not a.no_gather
 
     if a.plumbing_only:
         chunked, ok = plumbing_pass(a, rank, world, dist, dev)
@@ -310,7 +456,8 @@ def main():
         if gather and a.gather_mode == "end":
             def _rollout_all(xx, oo):
                 eng.rollout(xx, T, param=param, to_x=True, out=oo)
-            chunked = parallel.EndGatherRollout(_rollout_all, (args.in_channels, args.Ly, args.Lx), B, T, dev, gather=True)
+            chunked = parallel.EndGatherRollout(_rollout_all, (args.in_channels, args.Ly, args.Lx), B, T, dev, gather=True,
+                                                collective_at_world1=force_dist)
         elif gather:
             chunked = parallel.ChunkedGatherRollout(eng.encode, _rollout_latent, (args.in_channels, args.Ly, args.Lx),
                                                     B, T, a.gather_chunk, dev, gather=True)
@@ -331,7 +478,7 @@ def main():
     dt = time.perf_counter() - t0
     if chunked is not None and hasattr(chunked, "finish_timing"):
         chunked.finish_timing()
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -358,7 +505,7 @@ def main():
                    "streams": "single stream" if a.serial else "propagator + 3 decode streams per GPU"},
         "batch_steps_per_s": value / B,
     }
-    if world > 1:
+    if dist is not None:
         # self-describing multi-GPU record: what the backend saw, what moved, what of it was exposed
         shard_bytes = 4 * B * T * (2 * 8 * 8 if a.plumbing_only else args.in_channels * args.Ly * args.Lx)
         exp = getattr(chunked, "exposed_ms", None) if chunked is not None else None
@@ -371,13 +518,22 @@ def main():
             "exposed_gather_ms_rank0": (sum(exp[-a.steps:]) / max(1, len(exp[-a.steps:]))) if exp else None,
             "note": "end: the single gather is fully exposed (measured between the rollout's last kernel and the gather's "
                     "completion on rank 0); chunked: only the last block's gather is exposed (not separately timed)"}
+        if force_dist:
+            # ONE rank: nothing crosses xGMI, this is not a scaling measurement.  What it shows: the RCCL communicator comes
+            # up in this process, all_gather_into_tensor runs on the real shard and receive-buffer sizes inside the timed
+            # region, and the gathered buffer is the shard, bit for bit
+            full = chunked.assemble() if chunked is not None else None
+            result["multi_gpu"]["force_dist"] = True
+            result["multi_gpu"]["gathered_equals_shard"] = bool(full is not None and full.data_ptr() != chunked.out.data_ptr()
+                                                                and torch.equal(full, chunked.out))
+            result["multi_gpu"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if a.dist_backend == "nccl" else None
     if a.plumbing_only:
         result["data"] = "plumbing-only: orchestration without compute (value is NOT a measurement)"
         result["plumbing_ok"] = bool(ok)
         result["dist_backend"] = a.dist_backend
         if rank == 0:
             print(json.dumps(result))
-        if world > 1:
+        if dist is not None:
             dist.destroy_process_group()
         if not ok:
             sys.exit(3)
@@ -389,47 +545,42 @@ def main():
         result["check"] = golden_check(a.preset, T, src[:2].cpu().numpy(), fixture)
 
     if rank == 0 and not a.no_roofline:
-        # per-kernel-class HIP-event timing of one more pass (events recorded around every launch inside the engine,
-        # on the stream the kernel is launched on).  The engine runs this diagnostic pass single-stream, so kernel
-        # durations are not inflated by co-running kernels; it is kept out of `value`'s timed region.
+        # per-kernel HIP-event timing of one more pass (events recorded around every launch inside the engine, on the
+        # stream the kernel is launched on).  The engine runs this diagnostic pass single-stream, so kernel durations are
+        # not inflated by co-running kernels; it is kept out of `value`'s timed region.
         eng.timing_enable(True)
         eng.rollout(x, T, param=param, to_x=True, out=out)
         torch.cuda.synchronize()
         tm = eng.timing()
         eng.timing_enable(False)
-        k = tm.get("conv3x3_mfma")
-        tot_flops = sum(v["flops"] for v in tm.values())
+        classes = {n: v for n, v in tm.items() if "/" not in n}
+        forms = {n: v for n, v in tm.items() if "/" in n}
+        tot_flops = sum(v["flops"] for v in classes.values())
         result["path_tflops_per_gpu"] = tot_flops * a.steps * n_gpus / dt / 1e12 / n_gpus
-        if k:
-            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
-            peak = F16_MFMA_PEAK_TFLOPS / SPLIT_EXEC_PER_ALGO
-            result["roofline"] = {
-                "kernel": "conv3_bf16x3_kernel<..., SPL=2> (3x3 implicit GEMM; fp32 operands as 2 fp16 terms on v_mfma_f32_32x32x16_f16, fp32 accumulate)",
-                "bound": "mfma",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "peak_basis": "algorithmic fp32 FLOP: dense fp16 MFMA peak %.1f / %.2f executed fp16 FLOP per algorithmic FLOP "
-                              "(3 products x 10/9 tap padding).  The three convolutions behind a 2x nearest upsample run in "
-                              "their phase-decomposed four-tap form and execute only 1.33 per algorithmic FLOP: the class's "
-                              "algorithmic rate counts their full nine-tap FLOP, the peak keeps the nine-tap accounting"
-                              % (F16_MFMA_PEAK_TFLOPS, SPLIT_EXEC_PER_ALGO),
-                "executed_f16_tflops": ach * SPLIT_EXEC_PER_ALGO,
-                "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-                # HBM bytes per launch from the committed PMC passes (number, bytes); provenance in traffic_detail
-                "traffic": (traffic_from_profiles("conv3x3") or {}).get("hbm_bytes_per_launch"),
-                "traffic_detail": traffic_from_profiles("conv3x3"),
-                "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
-                "algorithmic_flop_per_launch": k["flops"] / k["launches"],
-                "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
-                "mode": "single-stream diagnostic pass (python bench.py --serial reproduces it under rocprofv3); the class "
-                        "average includes the few stride-2 / thin 3x3 convs that stay on the fp32-MFMA kernel",
-                "whole_path_algorithmic_tflops": result["path_tflops_per_gpu"],
-            }
-        tot = sum(v["ms"] for v in tm.values())
+        result["roofline"] = roofline_record(forms, classes, result["ms_per_step"], result["path_tflops_per_gpu"])
+        tot = sum(v["ms"] for v in classes.values())
         result["kernel_classes"] = {n: {"ms": round(v["ms"], 3), "share": round(v["ms"] / tot, 4),
                                         "launches": v["launches"],
                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                                         "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
-                                    for n, v in sorted(tm.items(), key=lambda kv: -kv[1]["ms"])}
+                                    for n, v in sorted(classes.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not force_dist and not a.no_check and not a.no_check_stable and (a.preset, T) in STABLE_FIXTURES and B >= 2:
+        # the same shape on the `stable` weight variant (lns_amd.filler): the real reference is reproducible over the WHOLE
+        # horizon there, so the north star's 1e-4 is gated at every stored step up to the last.  Un-timed extra rollout.
+        try:
+            _, model_s, _ = build_model(a.preset, dev, "stable")
+            xs = x.clone()
+            xs[:2] = torch.from_numpy(filler.normal("x", (2, args.in_channels, args.Ly, args.Lx), 7)).to(dev)
+            ps = None
+            if param is not None:
+                ps = param.clone()
+                ps[:2] = torch.from_numpy(filler.uniform01("param", 2, 7).astype("float32")).to(dev)
+            model_s._engine(xs).rollout(xs, T, param=ps, to_x=True, out=out)
+            torch.cuda.synchronize()
+            result["check_stable"] = golden_check(a.preset, T, out[:2].cpu().numpy(), STABLE_FIXTURES[(a.preset, T)])
+            del model_s
+        except Exception as ex:      # never lose the main line over a side record
+            result["check_stable"] = {"error": repr(ex)[:300], "pass": False}
     if rank == 0 and world == 1 and not a.no_strict_fp32:
         # the same workload with every convolution / the FABlock sandwich on the exact-fp32 matrix instruction
         # (v_mfma_f32_32x32x2_f32): a child process, because the arithmetic is chosen when the library packs the weights
@@ -447,6 +598,23 @@ def main():
             result["strict_fp32"] = rec
         except Exception as ex:      # never lose the main line over the side record
             result["strict_fp32"] = {"error": repr(ex)[:300]}
+    if rank == 0 and world == 1 and not force_dist and not a.no_rccl_world1 and a.dist_backend == "nccl":
+        # RCCL readiness on a one-GPU box: a child process initialises the nccl (= RCCL) backend with ONE rank before any
+        # other GPU call and runs the config-5 per-GPU shard (B=64, T=256: 3.22 GB) with the end-of-rollout
+        # all_gather_into_tensor in the timed region.  Nothing crosses xGMI: NOT a scaling number.
+        cmd = [sys.executable, os.path.abspath(__file__), "--force-dist", "--preset", "ns2d_128", "--batch", "64", "--rollout", "256",
+               "--steps", "1", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-strict-fp32", "--no-check"]
+        if a.device is not None:
+            cmd += ["--device", str(a.device)]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            rec = json.loads(p.stdout.strip().splitlines()[-1])
+            result["rccl_world1"] = {"multi_gpu": rec.get("multi_gpu"), "value": rec["value"], "unit": rec["unit"],
+                                     "ms_per_step": rec["ms_per_step"], "workload": rec["config"]["workload"],
+                                     "note": "one rank: the RCCL communicator, the collective and the [world*B,T,C,H,W] receive "
+                                             "buffer at config 5's per-GPU sizes; no scaling claim"}
+        except Exception as ex:
+            result["rccl_world1"] = {"error": repr(ex)[:300]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # bounded sample of the same workload (about 15 s of host time)
         cb, ct = (8, 32) if a.preset == "ns2d_128" else (4, 16)
@@ -456,7 +624,7 @@ def main():
             result["speedup_vs_reference_equivalent_cpu"] = value / result["cpu_baseline"]["reference_equivalent"]
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -229,6 +229,11 @@ int lns_timing_enable(lns_engine* e, int on);
 int lns_timing_count(const lns_engine* e);
 int lns_timing_info(const lns_engine* e, int index, char* name, int name_capacity,
                     double* total_ms, int64_t* launches, double* flops, double* bytes);
+/* Records named "class/form" follow the per-class ones: the same launches split by kernel form (nine-tap / four-tap /
+ * fp32-MFMA 3x3, streaming / input-stationary / fused 1x1, ...).  mfma_flops: FLOP the record's launches EXECUTED on the
+ * matrix pipe -- the three products of the split-operand scheme and every padded tap slot, channel and tile included --
+ * in FLOP of the form's instruction ("f16x2 ...": fp16 MFMA, "fp32 MFMA ...": fp32 MFMA); `flops` above stays algorithmic. */
+int lns_timing_mfma_flops(const lns_engine* e, int index, double* mfma_flops);
 
 /* Build-time features of this library: "experimental" = compiled with -DLNS_EXPERIMENTAL (the measured-slower kernel
  * forms behind op-level variants 15 / 16 / 18 / 19 exist; the shipped library does not carry them).  1 / 0; -1: unknown name.
@@ -240,7 +245,10 @@ int lns_build_has(const char* feature);
  *   y = act_out( conv(act_in(x * scale + shift)) + bias + badd ) + residual
  * x [B,Cin,Hin,Win] optionally nearest-resized to (Hv,Wv) before padding;
  * w [Cout,Cin,k,k] HOST pointer; ss [B,Cin,2] device (scale,shift) or NULL;
- * act: 0 none, 1 swish, 2 gelu.  tile_variant <0 = automatic.
+ * act: 0 none, 1 swish, 2 gelu.  tile_variant <0 = automatic; >= 0: a kernel / tile form (lns_kernels.h ConvVariant) in
+ * the low byte, plus tensor layouts: | 0x100 = x is channel-octet-interleaved ("OCT8": [Cin/8][Hin*Win][8] per sample,
+ * Cin % 8 == 0), | 0x200 = y and residual are OCT8 ([Cout/8][Hout*Wout][8]) -- the engine's layout of conv <-> conv
+ * intermediates.
  * amax_out (device, [B][16] unsigned, zero-initialised by the caller, or NULL): the maximum over the 16 words of
  * sample b is the IEEE bit pattern of max |y[b]| -- the side channel from which the split-operand (f16x2) kernels of a plan derive their per-sample
  * power-of-two activation scale.  The entry point computes the same quantity for x itself before the launch. */

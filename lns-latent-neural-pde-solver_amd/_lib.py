@@ -64,7 +64,7 @@ SYMBOLS = [
     "lns_encode", "lns_encode_cond", "lns_encode_affine", "lns_decode", "lns_propagate", "lns_rollout", "lns_rollout_latent", "lns_check_finite", "lns_set_option",
     "lns_train_workspace_bytes", "lns_train_forward", "lns_train_backward",
     "lns_trace_enable", "lns_trace_count", "lns_trace_info", "lns_trace_copy",
-    "lns_timing_enable", "lns_timing_count", "lns_timing_info", "lns_build_has",
+    "lns_timing_enable", "lns_timing_count", "lns_timing_info", "lns_timing_mfma_flops", "lns_build_has",
     "lns_op_conv2d", "lns_op_conv_pair_stress", "lns_op_groupnorm_stats", "lns_op_attention", "lns_op_fa_sandwich", "lns_op_fourier_block",
     "lns_fourier_block_create", "lns_fourier_block_forward", "lns_fourier_block_destroy", "lns_metric_rel_l2", "lns_metric_rel_l2_ch",
 ]
@@ -134,6 +134,7 @@ def lib():
     L.lns_timing_count.argtypes = [vp]
     L.lns_timing_info.argtypes = [vp, i, c.c_char_p, i, c.POINTER(c.c_double), i64p,
                                   c.POINTER(c.c_double), c.POINTER(c.c_double)]
+    L.lns_timing_mfma_flops.argtypes = [vp, i, c.POINTER(c.c_double)]
     L.lns_op_conv2d.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, i, i, i, i, i, i,
                                 vp, i, i, vp, vp, vp, i, vp, vp]
     L.lns_op_groupnorm_stats.argtypes = [vp, i, i, i, i, c.c_float, vp, vp, vp, vp, vp]

@@ -609,6 +609,27 @@ struct Planner {
         }
         op.flops = 2.0 * B * g.Hout * g.Wout * (double)pk.cout * pk.cin * k * k;
         op.bytes = 4.0 * B * ((double)in.C * in.H * in.W + (double)pk.cout * g.Hout * g.Wout * (res ? 2 : 1));
+        {   // executed matrix-pipe FLOP of the launch: every block runs whole tiles, whole channel stages and whole tap slots
+            const double tiles = (double)B * g.tiles_x * g.tiles_y * g.cout_tiles * vi.TM * vi.TN;
+            if (cv_is_f16x2_3x3(g.variant)) {           // 3 products; 10 tap slots for 9 taps, or 4 phases x 4 taps
+                op.mfma_flops = tiles * pk.Cin_pad * (up2 ? 4.0 * 4.0 : 10.0) * 3.0 * 2.0;
+                op.form = up2 ? (fuse_pack >= 0 ? "f16x2 3x3 four-tap phase form + fused 1x1" : "f16x2 3x3 four-tap phase form")
+                              : (fuse_pack >= 0 ? "f16x2 3x3 nine-tap + fused 1x1" : "f16x2 3x3 nine-tap");
+                if (fuse_pack >= 0) op.mfma_flops += tiles * (up2 ? 4.0 : 1.0) * 64.0 * 3.0 * 2.0;
+            } else if (g.variant == CV_B64 || g.variant == CV_B32) {
+                op.mfma_flops = tiles * pk.Cin_pad * 10.0 * 6.0 * 2.0; op.form = "bf16x3 3x3 nine-tap";
+            } else if (g.variant == CV_B1) {
+                const int cp32 = (pk.Cin_pad + 31) / 32 * 32;
+                op.mfma_flops = tiles * cp32 * (convb1_is_f16() ? 3.0 : 6.0) * 2.0;
+                op.form = a.ct_per_block ? "f16x2 1x1 input-stationary" : (fuse_pack >= 0 ? "f16x2 1x1 + fused 1x1" : "f16x2 1x1 streaming");
+                if (fuse_pack >= 0) op.mfma_flops += tiles * 64.0 * 3.0 * 2.0;
+            } else if (g.variant == CV_THIN) {
+                op.form = "thin 1x1 projection (VALU)";
+            } else {
+                op.mfma_flops = tiles * pk.Cin_pad * (double)(k * k) * 2.0 + (fuse_pack >= 0 ? tiles * 64.0 * 2.0 : 0.0);
+                op.form = k == 3 ? "fp32 MFMA 3x3" : "fp32 MFMA 1x1";
+            }
+        }
         if (fuse_pack >= 0) {
             const ConvPack& p2 = e->packs[fuse_pack];
             if (!can_fuse_1x1(pk, p2)) throw std::runtime_error("cannot fuse 1x1 into " + name);
@@ -688,6 +709,12 @@ struct Planner {
             op.at.n = n; op.at.scale = (float)std::pow((double)l.dim_head, -0.5); op.at.o = as_ptr<float>(o.ptr);
             op.at.amax_in = qkv.amax ? as_ptr<const unsigned>(qkv.amax) : nullptr;
             op.flops = 4.0 * B * l.heads * (double)n * n * l.dim_head;
+            {
+                const bool f16 = op.at.amax_in != nullptr && getenv("LNS_ATTN_FP32") == nullptr;
+                const double np_ = (n + 31) / 32 * 32;
+                op.mfma_flops = 4.0 * B * l.heads * np_ * np_ * l.dim_head * (f16 ? 3.0 : 1.0);
+                op.form = f16 ? "f16x2 attention" : "fp32 MFMA attention";
+            }
             op.bytes = 4.0 * B * 4.0 * inner * n;
             plan->ops.push_back(op);
         }
@@ -815,6 +842,12 @@ struct Planner {
             op.fs.b_rev = no_rev ? 0 : 1;
             op.flops = 2.0 * B * heads * dh * ((double)H * W * W + (double)H * H * W);
             op.bytes = 8.0 * B * heads * dh * H * W;
+            {   // 32 x 32 tiles; f16x2 form (three products) for planes of <= 96 columns with a recorded max |u|, else fp32 MFMA
+                const double Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+                const bool f16 = op.fs.amax_u != nullptr && W <= 96 && getenv("LNS_FA_SANDWICH_FP32") == nullptr;
+                op.mfma_flops = 2.0 * B * heads * dh * (Hp * Wp * Wp + Hp * Hp * Wp) * (f16 ? 3.0 : 1.0);
+                op.form = f16 ? "f16x2 FABlock sandwich" : "fp32 MFMA FABlock sandwich";
+            }
             plan->ops.push_back(op);
         }
         arena.release(kx_off); arena.release(ky_off);
@@ -1530,17 +1563,23 @@ struct Runner {
             e->timing.resize(CLS_COUNT);
             for (int i = 0; i < CLS_COUNT; ++i) e->timing[i].name = kClsName[i];
         }
+        auto named = [&](const std::string& nm) {
+            for (TimeRec& r : e->timing) if (r.name == nm) return &r;
+            e->timing.emplace_back();
+            e->timing.back().name = nm;
+            return &e->timing.back();
+        };
         for (EvPair& ev : evs) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, ev.a, ev.b);
-            TimeRec* t = nullptr;
-            if (!by_name) t = &e->timing[ev.cls];
-            else {
-                const std::string nm = std::string(kClsName[ev.cls]) + ":" + ev.op->name;
-                for (TimeRec& r : e->timing) if (r.name == nm) { t = &r; break; }
-                if (!t) { e->timing.emplace_back(); t = &e->timing.back(); t->name = nm; }
-            }
-            t->ms += ms; t->launches += 1; t->flops += ev.op->flops; t->bytes += ev.op->bytes;
+            TimeRec* t[2] = {nullptr, nullptr};
+            if (!by_name) {
+                // per class, and per kernel FORM inside the class ("class/form": nine-tap / four-tap / fp32-MFMA 3x3, ...)
+                if (ev.op->form[0]) t[1] = named(std::string(kClsName[ev.cls]) + "/" + ev.op->form);
+                t[0] = &e->timing[ev.cls];        // (after named(): emplace_back may move the vector)
+            } else t[0] = named(std::string(kClsName[ev.cls]) + ":" + ev.op->name);
+            for (TimeRec* r : t)
+                if (r) { r->ms += ms; r->launches += 1; r->flops += ev.op->flops; r->bytes += ev.op->bytes; r->mfma_flops += ev.op->mfma_flops; }
             (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
         }
         evs.clear();
@@ -2091,6 +2130,12 @@ int lns_timing_info(const lns_engine* e, int i, char* name, int cap, double* ms,
     return LNS_OK;
 }
 
+int lns_timing_mfma_flops(const lns_engine* e, int i, double* mfma_flops) {
+    if (!e || i < 0 || i >= (int)e->timing.size() || !mfma_flops) return LNS_EINVAL;
+    *mfma_flops = e->timing[i].mfma_flops;
+    return LNS_OK;
+}
+
 // ---- kernel-level entry points (tests) ------------------------------------------
 int lns_build_has(const char* feature) {
     if (!feature) return -1;
@@ -2124,6 +2169,10 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     if (!x || !w_host || !y || (ksize != 1 && ksize != 3)) return LNS_EINVAL;
     if (act_in != ACT_NONE && act_in != ACT_SWISH) return LNS_EINVAL;   // prologue: GroupNorm scale/shift + Swish only
     OPCHK(init_kernels());
+    // test code: tensor layouts in the high bits of tile_variant (>= 0 only): 0x100 = x is OCT8 ([Cin/8][H*W][8] per sample),
+    // 0x200 = y and the residual are OCT8 (include/lns.h)
+    const int layout = tile_variant >= 0 ? (tile_variant & 0x300) : 0;
+    if (tile_variant >= 0) tile_variant &= 0xff;
     const bool stationary = tile_variant == 8;      // test code: 1x1 bf16x3 kernel in its input-stationary form
     if (stationary) tile_variant = CV_B1;
     const bool w8 = tile_variant == 19;             // test code: f16x2 3x3 kernel in its 8-wave form (conv3_w8.inc)
@@ -2217,6 +2266,8 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
         if (!convur_fits(a)) return LNS_EINVAL;
     }
     a.w8 = w8 ? 1 : (forced ? -1 : 0);              // a forced tile variant means that kernel
+    a.x_oct = (layout & 0x100) ? 1 : 0; a.y_oct = (layout & 0x200) ? 1 : 0;
+    if ((a.x_oct && (Cin & 7)) || (a.y_oct && (Cout & 7))) return LNS_EINVAL;
     if (stationary) {
         if (pk.Cin_pad > 64) return LNS_EINVAL;
         a.ct_per_block = g.cout_tiles < 3 ? g.cout_tiles : 3;

@@ -82,6 +82,11 @@ struct Op {
     std::string name;
     int cls = 0;          // timing class
     double flops = 0, bytes = 0;
+    // what the launch EXECUTES on the matrix pipe (padding of taps / channels / tiles and the three products of the
+    // split-operand scheme included), in FLOP of the instruction's own dtype; `form` names the kernel form and the pipe
+    // ("f16x2 ...": v_mfma_f32_32x32x16_f16, "fp32 ...": v_mfma_f32_32x32x2_f32, others: no matrix work booked)
+    double mfma_flops = 0;
+    const char* form = "";
     int variant = 0;
     ConvArgs conv;
     GnStatsArgs gn;
@@ -124,7 +129,7 @@ struct Plan {
 struct ExtT { const void* ptr = nullptr; long bs = 0; long bs2 = 0; int bdiv = 0; };
 
 struct TraceRec { std::string name; int B, C, H, W; std::vector<float> data; };
-struct TimeRec { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
+struct TimeRec { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0, mfma_flops = 0; };
 
 }  // namespace lns
 

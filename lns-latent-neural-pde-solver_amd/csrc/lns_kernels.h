@@ -89,6 +89,12 @@ struct ConvArgs {
     // function of the layer only), the kernel uses it as is -- no per-sample maximum, no reduction in the prologue
     int bound_final;
     unsigned* amax_out;    // [B] or null: atomic max of the bit patterns of |y| over everything this launch stores
+    // Channel-octet-interleaved activations ("OCT8"): a sample is [C/8][H*W][8] fp32 instead of planar [C][H*W] -- the 8
+    // channels of one K stage of a pixel are 32 contiguous bytes (two 16-byte loads instead of eight dword gathers), and the
+    // four consecutive couts a lane holds of a 32x32 MFMA D tile are one 16-byte store.  A per-tensor planner property of
+    // conv <-> conv intermediates (C % 8 == 0; x, z, y and everything the plane-wise kernels read stay NCHW).
+    // x_oct: the input is OCT8 (f16x2 3x3 kernels, split-operand 1x1 kernels); y_oct: the output AND the residual are.
+    int x_oct, y_oct;
 #ifdef LNS_TS
     long long* dbg_ts;     // diagnostic build only: [blocks][8] phase timestamps (100 MHz wall clock) + hardware ids
 #endif

@@ -788,6 +788,9 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 }
 
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
+    // OCT8 tensors: inputs of the f16x2 3x3 kernels, outputs of the kernels with the shared split-operand epilogue
+    if (a.x_oct && !(cv_is_f16x2_3x3(variant) && !cv_is_pc(variant))) return hipErrorInvalidValue;
+    if (a.y_oct && !((cv_is_split_3x3(variant) && !cv_is_pc(variant)) || variant == CV_B1)) return hipErrorInvalidValue;
     if (cv_is_pc(variant)) return launch_conv_pc(variant == CV_P256 ? 2 : 1, a, s);
     if (cv_is_split_3x3(variant)) return launch_conv_bf16x3(variant, a, s);
     if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
@@ -930,7 +933,25 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     // epilogue arithmetic instead of one round trip per stored element (y may alias nothing, but the compiler
     // cannot know and would not move a load above an earlier store)
     float rv[MT][NT][16];
-    if (rb && (long)a.Cout * HWo * 4 < (1L << 31)) {
+    if (rb && a.y_oct) {
+        // OCT8 residual ([Cout/8][HWo][8], planner: Cout % 8 == 0, tensor < 2 GB): the lane's four consecutive couts of
+        // register group g are 16 contiguous bytes; octet row in the VGPR offset so that the range check masks a ragged
+        // cout tile, a lane without a pixel starts at 2^31
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rb), 0, a.Cout * HWo * 4, 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned vo = pix[nt] >= 0 ? (unsigned)(pix[nt] * 32 + kh * 16) : 0x80000000u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned ro = (unsigned)(((ct * TM + mt * 32) / 8 + g) * HWo * 32);
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(vo + ro), 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rv[mt][nt][4 * g + j] = __uint_as_float(t[j]);
+                }
+        }
+    } else if (rb && (long)a.Cout * HWo * 4 < (1L << 31)) {
         // through a buffer descriptor of the sample's residual tensor, addressed like the stores below (lane offset in
         // one VGPR, channel row in the scalar offset); what lies outside the tensor reads as zero and is never stored
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rb), 0, a.Cout * HWo * 4, 0x00020000);
@@ -1115,7 +1136,32 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 #else
     constexpr bool kFastStore = true;
 #endif
-    if (kFastStore && (ct + 1) * TM <= a.Cout && ybytes < (1L << 31) && __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull) {
+    if (a.y_oct) {
+        // OCT8 output: one 16-byte store per register group (4 per 32-cout block) instead of 16 dword stores; the hardware
+        // range check drops lanes without a pixel (offset 2^31) and octet rows past Cout (ragged cout tile)
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)ybytes, 0x00020000);
+        const unsigned nb = (unsigned)ybytes;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned vo = pix[nt] >= 0 ? (unsigned)(pix[nt] * 32 + kh * 16) : 0x80000000u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned vr = vo + (unsigned)(((ct * TM + mt * 32) / 8 + g) * HWo * 32);
+                    u32x4 t;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[mt][nt][4 * g + j];
+                        if (rb) v += rv[mt][nt][4 * g + j];
+                        t[j] = __float_as_uint(v);
+                        am = max(am, vr < nb ? abs_bits(v) : 0u);
+                        if (stats) sb[(mt * 32 + drow(4 * g + j, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(t, yr, (int)vr, 0, 0);
+                }
+        }
+    } else if (kFastStore && (ct + 1) * TM <= a.Cout && ybytes < (1L << 31) && __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull) {
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)ybytes, 0x00020000);
         if (rb) {
 #pragma unroll
@@ -1270,8 +1316,11 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     }
 }
 
-template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3, int NTAP = 9>
+template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3, int NTAP = 9, bool XOCT = false>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
+    // XOCT: the input tensor is channel-octet-interleaved ([Cin/8][Hin*Win][8] per sample, ConvArgs::x_oct; Cin % 8 == 0):
+    // the 8 channels of a K stage of a patch pixel are 32 contiguous bytes -- two 16-byte buffer loads per unit and stage
+    // instead of eight dword gathers out of eight channel planes (same values into the same registers: same bits).
     // NTAP = 4: the 3x3 convolution of a 2x nearest-upsampled tensor, PHASE-DECOMPOSED.  Output pixel (2i + pa, 2j + pb)
     // only sees the 2 x 2 source neighbourhood rows {i-1+pa, i+pa} x columns {j-1+pb, j+pb}, with the 3x3 taps that
     // fall on the same source pixel summed on the host (pa = 0: rows {ky 0 | ky 1+2}, pa = 1: {ky 0+1 | ky 2}; columns
@@ -1373,7 +1422,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         for (int u = 0; u < NU; ++u) {
             const int p = tid + u * NTHR;
             const bool ok = p < PLANE && sy[u] >= 0 && sx[u] >= 0;
-            udm[u] = ok ? (unsigned)(sy[u] * a.Win + sx[u]) * 4u : 0u;
+            udm[u] = ok ? (unsigned)(sy[u] * a.Win + sx[u]) * (XOCT ? 32u : 4u) : 0u;
             uok[u] = ok ? 1.0f : 0.0f;                          // times the activation scale once the bound is known
             uslot[u] = (p < PLANE ? p : PLANE) * UB;
         }
@@ -1429,6 +1478,16 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // (finite data) and meets zero weights.
     const int cin_m1 = a.Cin - 1, hw4 = HWin * 4;
     auto load_pair = [&](int u, int cp, int c0) __attribute__((always_inline)) {
+        if (XOCT) {
+            // OCT8: channel pairs (0, 1) and (2, 3) of a stage arrive together, by ONE 16-byte load issued when the later pair
+            // of the half is asked for (its registers are free by then: both pairs of the previous stage have been split)
+            if (cp & 1) {
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)udm[u] + 8 * (cp - 1), (c0 >> 3) * (hw4 * 8), 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pv[u][2 * (cp - 1) + e] = __uint_as_float(t[e]);
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int c = c0 + 2 * cp + e;
@@ -2392,16 +2451,26 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<2, 2, false, 2, 2>), grid, dim3(256), lds, s, a);
         return hipGetLastError();
     }
+    if (a.x_oct && (a.up2 == 2 || a.w8 == 1)) return hipErrorInvalidValue;       // (the experimental forms read planar tensors)
     if (variant == CV_F64 && a.up2 == 2) return launch_conv_up2r(a, s);     // ... with the source patch resident in LDS (conv3_up2r.inc)
+    // OCT8 tensors (ConvArgs::x_oct / y_oct): whole octets, 32-bit byte offsets
+    if ((a.x_oct && ((a.Cin & 7) || (long)a.Cin * a.Hin * a.Win * 4 >= (1L << 31) || !cv_is_f16x2_3x3(variant) || variant == CV_F256)) ||
+        (a.y_oct && ((a.Cout & 7) || (long)a.Cout * a.Hout * a.Wout * 4 >= (1L << 31))))
+        return hipErrorInvalidValue;
+#define LNS_LAUNCH_F16X2(NU_, FUSE_, MT_, NTAP_, GRID)                                                                    \
+    do {                                                                                                                  \
+        if (a.x_oct) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, NU_, FUSE_, MT_, 2, NTAP_, true>), GRID, dim3(256), lds, s, a);  \
+        else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, NU_, FUSE_, MT_, 2, NTAP_, false>), GRID, dim3(256), lds, s, a);  \
+    } while (0)
     if (variant == CV_F64 && a.up2) {                     // phase-decomposed 2x nearest upsample + 3x3 (four taps per phase)
         const size_t lds = convb_lds_bytes(a, 64, 2, 2);
         dim3 gu(a.tiles_x * a.tiles_y * a.cout_tiles * 4, a.B);
         if (a.w2) {
-            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true, 2, 2, 4>), gu, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true, 2, 2, 4>), gu, dim3(256), lds, s, a);
+            if (two) LNS_LAUNCH_F16X2(2, true, 2, 4, gu);
+            else LNS_LAUNCH_F16X2(1, true, 2, 4, gu);
         } else {
-            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 2, 2, 4>), gu, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 2, 2, 4>), gu, dim3(256), lds, s, a);
+            if (two) LNS_LAUNCH_F16X2(2, false, 2, 4, gu);
+            else LNS_LAUNCH_F16X2(1, false, 2, 4, gu);
         }
         return hipGetLastError();
     }
@@ -2415,21 +2484,22 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     if (variant == CV_F64) {                              // two-term fp16 split
         const size_t lds = convb_lds_bytes(a, 64, 2, 2);
         if (a.w2) {
-            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, true, 2, 2>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, true, 2, 2>), grid, dim3(256), lds, s, a);
+            if (two) LNS_LAUNCH_F16X2(2, true, 2, 9, grid);
+            else LNS_LAUNCH_F16X2(1, true, 2, 9, grid);
         } else {
-            if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 2, 2>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 2, 2>), grid, dim3(256), lds, s, a);
+            if (two) LNS_LAUNCH_F16X2(2, false, 2, 9, grid);
+            else LNS_LAUNCH_F16X2(1, false, 2, 9, grid);
         }
         return hipGetLastError();
     }
     if (variant == CV_F32) {                              // f16x2, 32-cout tiles: a.cout_tiles counts those
         if (a.w2) return hipErrorInvalidValue;
         const size_t lds = convb_lds_bytes(a, 32, 2, 2);
-        if (two) hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 2, false, 1, 2>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((conv3_bf16x3_kernel<1, 1, false, 1, 2>), grid, dim3(256), lds, s, a);
+        if (two) LNS_LAUNCH_F16X2(2, false, 1, 9, grid);
+        else LNS_LAUNCH_F16X2(1, false, 1, 9, grid);
         return hipGetLastError();
     }
+#undef LNS_LAUNCH_F16X2
     if (variant == CV_B32) {                              // 32-cout tiles: a.cout_tiles counts those
         if (a.w2) return hipErrorInvalidValue;
         const size_t lds = convb_lds_bytes(a, 32, 3, 2);
@@ -4926,6 +4996,16 @@ hipError_t init_kernels() {
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2, 4>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true, 2, 2, 4>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true, 2, 2, 4>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 2, 2, 9, true>))       // OCT8-input instantiations (ConvArgs::x_oct)
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2, 9, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true, 2, 2, 9, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true, 2, 2, 9, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 2, 2, 4, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2, 4, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, true, 2, 2, 4, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, true, 2, 2, 4, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 1, false, 1, 2, 9, true>))
+    LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 1, 2, 9, true>))
     LNS_SET_LDS((conv3_bf16x3_kernel<2, 2, false, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<2, 2, true, 2, 2>))
     LNS_SET_LDS((conv3_bf16x3_kernel<1, 2, false, 2, 2>))

@@ -403,8 +403,11 @@ class Engine:
         for i in range(self._L.lns_timing_count(self._h)):
             self._check(self._L.lns_timing_info(self._h, i, name, len(name), ctypes.byref(ms), ctypes.byref(n),
                                                 ctypes.byref(fl), ctypes.byref(by)), "lns_timing_info")
+            mf = ctypes.c_double()
+            self._check(self._L.lns_timing_mfma_flops(self._h, i, ctypes.byref(mf)), "lns_timing_mfma_flops")
             if n.value:
-                out[name.value.decode()] = dict(ms=ms.value, launches=int(n.value), flops=fl.value, bytes=by.value)
+                out[name.value.decode()] = dict(ms=ms.value, launches=int(n.value), flops=fl.value, bytes=by.value,
+                                                mfma_flops=mf.value)
         return out
 
 

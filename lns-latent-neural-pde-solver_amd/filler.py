@@ -57,9 +57,44 @@ def normal(tag: str, shape, seed: int) -> np.ndarray:
     return ((acc - np.float32(2.0)) * np.float32(np.sqrt(3.0))).reshape(shape).astype(np.float32)
 
 
-def fill_tensor(key: str, shape, seed: int):
+# Filler variants.  "default": PyTorch-default scales everywhere -- the latent chain of such a random-init model amplifies
+# a rounding-sized perturbation by x50 (NS2d, 64 steps) to x1e5 (two-phase, 128 steps), so beyond t ~ 48 two correct fp32
+# implementations differ by 1e-3 ... 1 and long-horizon parity can only be judged against an ensemble.  "stable": the last
+# convolution of every residual branch of the propagator (DilatedResidualBlock conv.5 / ffn.3, train_stage2_ns2d.py:38-48;
+# conditional block cond_conv1.2 / ffn.3, train_stage2_twophase_conditional.py:47-58) is scaled by STABLE_GAIN, which makes
+# the chain non-expansive: the REAL reference's own fp32 runs then stay within a few 1e-5 of its fp64 run over the whole
+# horizon of BASELINE configs 3 / 4 / 5 (measured: tools/stable_filler_probe.py), and the north star's 1e-4 can be gated at
+# EVERY step (`*_stable` fixtures).  Same hash, same keys: a variant only rescales tensors.
+import re
+
+STABLE_GAIN = 0.25
+_RES_OUT = re.compile(r"propagator\.net\.\d+\.(conv\.5|ffn\.3|cond_conv1\.2)\.(weight|bias)$")
+
+
+def variant_gain(key: str, variant) -> float:
+    """Multiplier the variant applies to state_dict entry `key` ("default" / None: 1; "stable"; "gain=<g>": probing)."""
+    if variant in (None, "default"):
+        return 1.0
+    if variant == "stable":
+        g = STABLE_GAIN
+    elif isinstance(variant, str) and variant.startswith("gain="):
+        g = float(variant[5:])
+    else:
+        raise ValueError("unknown filler variant %r" % (variant,))
+    return g if _RES_OUT.search(key) else 1.0
+
+
+def fill_tensor(key: str, shape, seed: int, variant=None):
     """Synthetic value for state_dict entry `key`; None => keep module default
     (non-learned buffers such as rotary `inv_freq`)."""
+    v = _fill_default(key, shape, seed)
+    g = variant_gain(key, variant)
+    if v is not None and g != 1.0:
+        v = (v * np.float32(g)).astype(np.float32)
+    return v
+
+
+def _fill_default(key: str, shape, seed: int):
     shape = tuple(int(s) for s in shape)
     if key.endswith("inv_freq"):
         return None
@@ -81,12 +116,12 @@ def fill_tensor(key: str, shape, seed: int):
     return v.reshape(shape).astype(np.float32)
 
 
-def fill_state_dict(shapes: dict, seed: int) -> dict:
+def fill_state_dict(shapes: dict, seed: int, variant=None) -> dict:
     """shapes: {key: shape}.  Returns {key: float32 ndarray} for every key that
     the filler owns (buffers like inv_freq are omitted)."""
     out = {}
     for k, shp in shapes.items():
-        v = fill_tensor(k, shp, seed)
+        v = fill_tensor(k, shp, seed, variant)
         if v is not None:
             out[k] = v
     return out
@@ -97,24 +132,24 @@ def inv_freq(dim):
     return (1.0 / (10000 ** (np.arange(0, dim, 2, dtype=np.float32) / np.float32(dim)))).astype(np.float32)
 
 
-def synthetic_state_dict(shapes: dict, seed: int) -> dict:
+def synthetic_state_dict(shapes: dict, seed: int, variant=None) -> dict:
     """{key: ndarray} for a {key: shape} manifest: the deterministic filler for learned tensors, the analytic constant
     for rotary `inv_freq` buffers."""
-    sd = fill_state_dict(shapes, seed)
+    sd = fill_state_dict(shapes, seed, variant)
     for k, shp in shapes.items():
         if k.endswith("inv_freq"):
             sd[k] = inv_freq(2 * int(shp[0]))
     return sd
 
 
-def load_into_torch_module(module, seed: int):
+def load_into_torch_module(module, seed: int, variant=None):
     """Overwrite a torch module's parameters/buffers in place with the
     deterministic filler (used on the reference model and on the drop-in)."""
     import torch
     sd = module.state_dict()
     with torch.no_grad():
         for k, t in sd.items():
-            v = fill_tensor(k, tuple(t.shape), seed)
+            v = fill_tensor(k, tuple(t.shape), seed, variant)
             if v is not None:
                 t.copy_(torch.from_numpy(v).to(t.dtype))
     return module

@@ -88,12 +88,15 @@ class EndGatherRollout:
 
     rollout(x, out) writes out [B,T,C,H,W] in place."""
 
-    def __init__(self, rollout, frame_shape, B, T, device, group=None, gather=True):
+    def __init__(self, rollout, frame_shape, B, T, device, group=None, gather=True, collective_at_world1=False):
+        """collective_at_world1: issue the all-gather even when the process group has ONE rank (`bench.py --force-dist`:
+        the RCCL path -- communicator creation, the collective on the real shard size, the receive buffer -- executed
+        on a one-GPU box; the result must equal the shard bit for bit)."""
         self.rollout, self.group = rollout, group
         self.world = dist.get_world_size(group) if (gather and dist.is_initialized()) else 1
         self.out = torch.empty((B, T) + tuple(frame_shape), dtype=torch.float32, device=device)
         self.full = None
-        if self.world > 1:
+        if self.world > 1 or (collective_at_world1 and gather and dist.is_initialized()):
             self.full = torch.empty((self.world * B, T) + tuple(frame_shape), dtype=torch.float32, device=device)
         self.on_gpu = torch.device(device).type == "cuda"
         self.bufs = [self.out]

@@ -26,7 +26,7 @@ _FAMILY_SCRIPT = {
 }
 
 
-def build_reference_dynamics(args, weight_seed: int, dtype=torch.float32):
+def build_reference_dynamics(args, weight_seed: int, dtype=torch.float32, variant=None):
     """Reference `LatentDynamics(args)` (random init replaced by the filler),
     eval mode.  For family "sw_nonsquared" (BASELINE config 3) the reference has
     no shipped script: the SW propagator of train_stage2_SW.py:25-87 is paired
@@ -51,9 +51,22 @@ def build_reference_dynamics(args, weight_seed: int, dtype=torch.float32):
         model = LatentDynamics(args)
     else:
         model = mods[_FAMILY_SCRIPT[fam]].LatentDynamics(args)
-    filler.load_into_torch_module(model, weight_seed)
+    filler.load_into_torch_module(model, weight_seed, variant)      # variant: lns_amd.filler ("stable": non-expansive chain)
     model = model.to(dtype).eval()
     return model
+
+
+def patch_cond_embedding_f64():
+    """modules/cond_utils.py:34 casts the conditional embedding to fp32 (`.float()`); an fp64 tie-breaker run of the
+    conditional propagator re-casts it to the input's dtype (module attribute patched in memory, no source edit)."""
+    mod = ref_shim.load_reference()["train_stage2_twophase_conditional"]
+    if not getattr(mod.fourier_embedding, "_lns_f64", False):
+        orig = mod.fourier_embedding
+
+        def fe64(t, dim, max_period=10000, _o=orig):
+            return _o(t, dim, max_period).to(t.dtype)
+        fe64._lns_f64 = True
+        mod.fourier_embedding = fe64
 
 
 def reference_predict(model, x, steps, param=None, to_x=True):

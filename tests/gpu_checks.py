@@ -29,10 +29,22 @@ def rng(seed):
     return np.random.default_rng(seed)
 
 
+def to_oct8(a):
+    """[B, C, H, W] -> the engine's channel-octet-interleaved layout [B, C/8, H*W, 8] (C % 8 == 0)."""
+    B, C, H, W = a.shape
+    return np.ascontiguousarray(a.reshape(B, C // 8, 8, H * W).transpose(0, 1, 3, 2))
+
+
+def from_oct8(a, C, H, W):
+    B = a.shape[0]
+    return np.ascontiguousarray(a.reshape(B, C // 8, H * W, 8).transpose(0, 1, 3, 2)).reshape(B, C, H, W)
+
+
 def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), up=None, ss=False, act_in=0,
               act_out=0, res=False, badd=False, bias=True, variant=-1, seed=0, xscale=1.0, sample_scales=None,
-              heavy_w=False, xdist="normal", fp64=False, ret_y=False):
+              heavy_w=False, xdist="normal", fp64=False, ret_y=False, xoct=False, yoct=False):
     """Returns (rel_l2 error, output shape) of lns_op_conv2d vs the oracle composition.
+    xoct / yoct: the input / the output and residual are handed to the kernel in the OCT8 layout (variant | 0x100 / 0x200).
     xscale / sample_scales: magnitude of the activations (per sample); heavy_w: heavy-tailed (Student-t, 2 dof)
     weights; xdist "lognormal": activations spread over several decades; fp64: additionally returns the error
     against an fp64 evaluation of the same composition (third element)."""
@@ -80,10 +92,13 @@ def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), u
     if res:
         res_v = r.standard_normal(ref.shape).astype(np.float32)
         ref = ref + res_v
-    xd = _dev(x)
+    xd = _dev(to_oct8(x) if xoct else x)
     y = torch.full(ref.shape, float("nan"), dtype=torch.float32, device="cuda")
     ssd = _dev(ssv) if ssv is not None else None
-    resd = _dev(res_v) if res_v is not None else None
+    resd = _dev(to_oct8(res_v) if yoct else res_v) if res_v is not None else None
+    if xoct or yoct:
+        assert variant >= 0
+        variant = variant | (0x100 if xoct else 0) | (0x200 if yoct else 0)
     baddd = _dev(badd_v) if badd_v is not None else None
     amax = torch.zeros((B, 16), dtype=torch.int32, device="cuda")
     rc = L.lns_op_conv2d(xd.data_ptr(), B, Cin, H, W, Hv, Wv, _hp(w), _hp(bv), Cout, k, stride, dil,
@@ -95,6 +110,8 @@ def conv_case(B, Cin, Cout, H, W, k=3, stride=1, dil=1, pad=None, mode=(1, 1), u
     assert rc == 0, "lns_op_conv2d rc=%d" % rc
     torch.cuda.synchronize()
     out = y.cpu().numpy()
+    if yoct:
+        out = from_oct8(out.reshape(B, Cout // 8, -1, 8), Cout, ref.shape[2], ref.shape[3])
     assert np.isfinite(out).all(), "non-finite / unwritten outputs"
     # amax side channel: bit pattern of max |y| per sample, exactly
     got = amax.cpu().numpy().view(np.float32).max(1)      # [B][16] sub-slots: the maximum is the sample's
@@ -215,6 +232,21 @@ for _c in UP2R_CASES:
 for _c in [dict(B=2, Cin=128, Cout=128, H=16, W=16, ss=True, act_in=1, mode=(1, 1)), dict(B=2, Cin=128, Cout=128, H=7, W=15, ss=True, mode=(0, 0), badd=True),
            dict(B=2, Cin=40, Cout=100, H=21, W=37, ss=True, act_in=1, res=True, mode=(0, 0)), dict(B=1, Cin=64, Cout=64, H=16, W=16, dil=2, mode=(1, 1), act_out=2)]:
     CONV_CASES.append(dict(k=3, variant=19, **_c))
+# OCT8 layouts of the f16x2 3x3 kernel (variants 11 / 13 / 17 with | 0x100 input, | 0x200 output + residual): every padding
+# mode, dilation, the phase form, prologue / epilogue features, ragged pixel tiles, ragged cout tiles (Cout % 64 != 0)
+OCT_CASES = [dict(B=2, Cin=64, Cout=64, H=32, W=32, mode=(1, 1), ss=True, act_in=1, res=True),
+             dict(B=2, Cin=128, Cout=128, H=16, W=16, dil=2, mode=(1, 1), ss=True, act_out=2),
+             dict(B=2, Cin=72, Cout=104, H=21, W=37, mode=(0, 0), ss=True, act_in=1, badd=True, res=True),
+             dict(B=3, Cin=128, Cout=128, H=7, W=15, mode=(0, 0), ss=True, act_out=2),
+             dict(B=2, Cin=64, Cout=128, H=12, W=24, dil=3, mode=(0, 1)),
+             dict(B=2, Cin=320, Cout=64, H=20, W=20, mode=(1, 1), ss=True, act_in=1)]
+for _c in OCT_CASES:
+    for _lay in (dict(xoct=True), dict(yoct=True), dict(xoct=True, yoct=True)):
+        CONV_CASES.append(dict(k=3, variant=11, **_c, **_lay))
+    CONV_CASES.append(dict(k=3, variant=13, xoct=True, yoct=True, **_c))
+for _c in UP2_CASES:
+    if _c["Cin"] % 8 == 0 and _c["Cout"] % 8 == 0:
+        CONV_CASES.append(dict(k=3, variant=17, xoct=True, yoct=True, **_c))
 # bf16x3 1x1 kernel (variant 7): channel counts below / above / not multiples of the 32-channel stage, ragged pixel
 # counts, prologue and epilogue features
 for _c in [dict(B=2, Cin=3, Cout=64, H=32, W=32, act_out=1), dict(B=2, Cin=16, Cout=128, H=16, W=16),
@@ -398,13 +430,13 @@ def conv2d_gpu(x, w, bias, k, pad=0, variant=-1):
     return y
 
 
-def build_models(args, weight_seed):
-    """(drop-in model on cuda, oracle) with identical deterministic weights."""
+def build_models(args, weight_seed, variant=None):
+    """(drop-in model on cuda, oracle) with identical deterministic weights (variant: lns_amd.filler, "stable")."""
     from helpers import synthetic_state_dict
     from lns_amd import dropin
     model = dropin.build_dynamics(args)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = synthetic_state_dict(shapes, weight_seed)
+    sd = synthetic_state_dict(shapes, weight_seed, variant)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.cuda()
     orc = lns_oracle.OracleDynamics(args, sd)

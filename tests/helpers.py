@@ -45,10 +45,16 @@ def inv_freq(dim):
     return filler.inv_freq(dim)
 
 
-def synthetic_state_dict(shapes, seed):
-    """{key: ndarray} for a {key: shape} manifest (lns_amd.filler.synthetic_state_dict)."""
+def synthetic_state_dict(shapes, seed, variant=None):
+    """{key: ndarray} for a {key: shape} manifest (lns_amd.filler.synthetic_state_dict).  variant: the fixture's
+    meta["filler_variant"] ("stable": non-expansive latent chain, `*_stable` fixtures)."""
     from lns_amd import filler
-    return filler.synthetic_state_dict(shapes, seed)
+    return filler.synthetic_state_dict(shapes, seed, variant)
+
+
+def case_variant(meta):
+    v = meta.get("filler_variant", "default")
+    return None if v == "default" else v
 
 
 # ---- SURVEY 8f-2: denormalise + relative-L2 metric fixtures (tests/golden/metrics.npz, tools/make_golden_metrics.py)

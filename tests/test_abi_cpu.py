@@ -156,13 +156,16 @@ def test_hot_loops_keep_their_instruction_budget():
     import loop_stats
     from lns_amd import _lib
     text = check_isa.disassemble(_lib.LIB_PATH)
-    segs = loop_stats.segments(text, "conv3_bf16x3_kernelILi1ELi1ELb0ELi2ELi2ELi9E", 30)
-    assert len(segs) == 4                                   # the four prologue modes of the nine-tap f16x2 kernel
-    valu = sorted(c["valu"] for _, c, _ in segs)
-    for _, c, v in segs:
-        assert c["mfma"] == 30 and c["vmem_load"] == 13 and c["ds_write"] == 7
-        assert v.get("v_lshl_add_u64", 0) == 0 and v.get("v_mad_i64_i32", 0) == 0
-    assert valu[0] <= 50 and valu[2] <= 90 and valu[3] <= 230, valu
+    # planar input (...Li9ELb0E): 8 dword gathers + 5 weight loads per stage; OCT8 input (...Li9ELb1E, ConvArgs::x_oct): the
+    # 8 channels of a patch pixel by two 16-byte loads -> 7 vector-memory instructions per stage
+    for sym, loads in (("conv3_bf16x3_kernelILi1ELi1ELb0ELi2ELi2ELi9ELb0E", 13), ("conv3_bf16x3_kernelILi1ELi1ELb0ELi2ELi2ELi9ELb1E", 7)):
+        segs = loop_stats.segments(text, sym, 30)
+        assert len(segs) == 4, sym                          # the four prologue modes of the nine-tap f16x2 kernel
+        valu = sorted(c["valu"] for _, c, _ in segs)
+        for _, c, v in segs:
+            assert c["mfma"] == 30 and c["vmem_load"] == loads and c["ds_write"] == 7, (sym, c)
+            assert v.get("v_lshl_add_u64", 0) == 0 and v.get("v_mad_i64_i32", 0) == 0
+        assert valu[0] <= 50 and valu[2] <= 90 and valu[3] <= 230, valu
     segs1 = loop_stats.segments(text, "conv1_bf16x3_kernelILb1ELb0", 12)        # streaming 1x1 kernel, 8-byte loads
     assert segs1 and min(c["valu"] - v.get("v_mov_b32_e32", 0) for _, c, v in segs1) <= 70
 

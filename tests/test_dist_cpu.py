@@ -177,6 +177,25 @@ def test_bench_launches_its_own_ranks():
     assert rec["multi_gpu"]["gather"] == "chunked" and rec["multi_gpu"]["gathers_per_rollout"] == 4
 
 
+def test_bench_force_dist_runs_the_collective_with_one_rank():
+    """`python bench.py --gpus 1 --force-dist`: the process group is created IN this process with ONE rank and the
+    end-of-rollout all_gather_into_tensor runs anyway, into a separate [world*B, T, C, H, W] buffer that must equal the shard
+    bit for bit.  CPU rehearsal of the RCCL readiness run (gloo, --plumbing-only); tests/test_gpu_parity.py runs it on RCCL."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "gloo",
+                        "--plumbing-only", "--steps", "2", "--warmup", "1", "--batch", "3", "--rollout", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    mg = rec["multi_gpu"]
+    assert rec["n_gpus"] == 1 and rec["plumbing_ok"] is True
+    assert mg["backend"] == "gloo" and mg["world_size_seen_by_backend"] == 1 and mg["force_dist"] is True
+    assert mg["gather"] == "end" and mg["gathers_per_rollout"] == 1 and mg["gathered_equals_shard"] is True
+    assert mg["bytes_contributed_per_rank"] == 4 * 3 * 5 * 2 * 8 * 8 and mg["bytes_received_per_rank"] == 0
+
+
 def test_bench_workload_labels_follow_the_preset():
     """metric / workload strings are derived from the preset (they were hard-coded to NS2d in round 1)."""
     sys.path.insert(0, ROOT)
@@ -185,4 +204,6 @@ def test_bench_workload_labels_follow_the_preset():
         assert label and wl
         for T, fx in fixtures.items():
             assert os.path.exists(os.path.join(ROOT, "tests", "golden", fx + ".npz")), fx
+    for (preset, T), fx in bench.STABLE_FIXTURES.items():
+        assert preset in bench.WORKLOADS and os.path.exists(os.path.join(ROOT, "tests", "golden", fx + ".npz")), fx
     assert "NS2d" in bench.WORKLOADS["ns2d_128"][0] and "two-phase" in bench.WORKLOADS["twophase_cond"][0]

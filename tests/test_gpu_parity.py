@@ -93,6 +93,27 @@ def test_conv_tile_variants_same_bits():
         assert np.array_equal(y11, y19), ("variant 19", kw)
 
 
+def test_conv_oct8_layouts_same_bits():
+    """The channel-octet-interleaved layout only changes where a value is loaded from / stored to: the f16x2 3x3 kernel gives
+    the SAME bits with an OCT8 input, an OCT8 output (+ residual), or both, as with planar tensors (64- and 32-cout tiles,
+    the phase form of the upsampling conv)."""
+    _need_gpu()
+    import gpu_checks as gc
+    import numpy as np
+    for kw in gc.OCT_CASES:
+        for v in (11, 13):
+            y0 = gc.conv_case(k=3, variant=v, seed=12, ret_y=True, **kw)[2]
+            for lay in (dict(xoct=True), dict(yoct=True), dict(xoct=True, yoct=True)):
+                y1 = gc.conv_case(k=3, variant=v, seed=12, ret_y=True, **kw, **lay)[2]
+                assert np.array_equal(y0, y1), (v, kw, lay)
+    for kw in gc.UP2_CASES:
+        if kw["Cin"] % 8 or kw["Cout"] % 8:
+            continue
+        y0 = gc.conv_case(k=3, variant=17, seed=13, ret_y=True, **kw)[2]
+        y1 = gc.conv_case(k=3, variant=17, seed=13, ret_y=True, xoct=True, yoct=True, **kw)[2]
+        assert np.array_equal(y0, y1), kw
+
+
 def test_upsampling_conv_resident_patch_same_bits():
     """The resident-patch form of the phase-decomposed upsampling conv (op-level variant 18: the split source patch of all
     channels staged once per source tile, four phases per block) gives the bits of the per-phase form (17)."""
@@ -197,13 +218,19 @@ def test_fa_sandwich_f16x2_domain(case):
         assert err < tol and e64 < tol, (shape, case, err, e64)
 
 
+# constructor flags no shipped config sets (modules/autoencoder2d.py:36-47): attention blocks in the encoder (FABlock2D /
+# SABlock with use_fa=False), two residual blocks per level -- on the ns2d_mini shape
+FLAG_VARIANTS = {"ns2d_mini+attn_enc": dict(use_attn_enc=True), "ns2d_mini+attn_enc_sa": dict(use_attn_enc=True, use_fa=False),
+                 "ns2d_mini+res2": dict(encoder_res_blocks=2, decoder_res_blocks=2)}
+
+
 @pytest.mark.parametrize("preset", ["ns2d_mini", "ns2d_128", "sw_half_periodic", "sw_96x192x5", "twophase",
-                                    "twophase_cond"])
+                                    "twophase_cond"] + sorted(FLAG_VARIANTS))
 def test_every_layer_matches_oracle(preset):
     _need_gpu()
     import gpu_checks as gc
     from lns_amd import config, filler
-    args = config.preset(preset)
+    args = config.preset(preset.split("+")[0], **FLAG_VARIANTS.get(preset, {}))
     x = filler.normal("x", (2, args.in_channels, args.Ly, args.Lx), 7)
     param = filler.uniform01("param", 2, 7).astype(np.float32) if args.family == "twophase_cond" else None
     rows = gc.layer_trace_compare(args, 1, x, param)
@@ -213,7 +240,8 @@ def test_every_layer_matches_oracle(preset):
 
 
 GOLDEN_CASES = ["ns2d_mini", "ns2d_mini_zeros", "ns2d_mini_sa", "ns2d_mini_nocoarse", "ns2d_64", "ns2d_128",
-                "sw_half_periodic", "sw_96x192x5", "twophase", "twophase_cond", "ns2d_mini_fourier"]
+                "sw_half_periodic", "sw_96x192x5", "twophase", "twophase_cond", "ns2d_mini_fourier",
+                "ns2d_mini_attn_enc", "ns2d_mini_attn_enc_sa", "ns2d_mini_res2"]
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
@@ -300,6 +328,90 @@ def test_long_horizon_rollout_vs_reference(case):
     nrm = np.sqrt((dec.astype(np.float64) ** 2).sum((-1, -2)))
     ok = g["ref_ens_err"].max(0) <= 1e-4
     np.testing.assert_allclose(nrm[:, ok], g["dec_norm_f64"][:, ok], rtol=1e-3)
+
+
+# FULL horizons of BASELINE configs 3 / 4 / 5 in a regime where parity means something: on the `stable`
+# filler variant (lns_amd.filler; the last convolution of every residual branch of the propagator x 0.25) the latent chain is
+# non-expansive, every member of the real reference's ten-member fp32 ensemble stays within 3e-5 of its fp64 run at every
+# step (tests/test_oracle_golden.py::test_stable_fixtures_are_reproducible_over_the_full_horizon), and the engine is gated
+# at the north star's 1e-4 against the reference's fp32 run at EVERY stored step, first to last -- no `reported, not gated`.
+STABLE_CASES = ["sw_96x192x5_T64_stable", "twophase_cond_T128_stable", "ns2d_128_T256_stable"]
+
+
+@pytest.mark.parametrize("case", STABLE_CASES)
+def test_full_horizon_rollout_vs_reference_stable(case):
+    _need_gpu()
+    import gpu_checks as gc
+    from helpers import case_variant
+    meta, g = load_golden(case)
+    assert meta["steps"][-1] == meta["T"] and case_variant(meta) == "stable"
+    args = case_args(meta)
+    model, _ = gc.build_models(args, meta["weight_seed"], case_variant(meta))
+    x, param = case_inputs(meta, args)
+    xd = torch.from_numpy(x).cuda()
+    T = meta["T"]
+    extra = (torch.from_numpy(param).cuda(),) if param is not None else ()
+    dec, lat = model.predict(xd, T, *extra, to_x=True, return_latents=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dec).all()
+    dec, lat = dec.cpu().numpy(), lat.cpu().numpy()
+    sub = meta["sub"]
+    ens = g["ref_ens_err_sub"]
+    report = []
+    for i, s in enumerate(meta["steps"]):
+        f = dec[:, s - 1][..., ::sub, ::sub]
+        e_dec, e64, e_lat = rel_l2(f, g["dec"][:, i]), rel_l2(f, g["dec_f64"][:, i]), rel_l2(lat[:, s - 1], g["lat"][:, i])
+        report.append((s, e_dec, e64, e_lat, float(ens[:, i].max())))
+        assert float(ens[:, i].max()) <= 3e-5, report          # the premise: the reference itself is reproducible here
+        assert e_dec < ROLLOUT_TOL and e64 < ROLLOUT_TOL and e_lat < ROLLOUT_TOL, report
+    print(case, "(step, decoded vs fp32 run, vs fp64 run, latent vs fp32 run, reference ensemble max)", report)
+    nrm = np.sqrt((dec.astype(np.float64) ** 2).sum((-1, -2)))
+    np.testing.assert_allclose(nrm, g["dec_norm_f64"], rtol=5e-4)
+
+
+@pytest.mark.timeout(300)
+def test_rccl_all_gather_with_one_rank_equals_the_shard():
+    """RCCL readiness on a one-GPU box: init_process_group("nccl", world_size=1) in THIS process, then
+    lns_amd.parallel.EndGatherRollout with the collective forced -- the HIP rollout writes the shard, ONE
+    all_gather_into_tensor (RCCL) copies it into the separate [world*B, T, C, H, W] buffer, which must equal the shard bit
+    for bit and the ungathered rollout.  (Nothing crosses xGMI with one rank: no scaling claim.)"""
+    _need_gpu()
+    import datetime
+    import socket
+    import torch.distributed as dist
+    import gpu_checks as gc
+    from lns_amd import config, filler, parallel
+    args = config.preset("ns2d_mini")
+    model, _ = gc.build_models(args, 1)
+    B, T = 2, 4
+    x = torch.from_numpy(filler.normal("x", (B, args.in_channels, args.Ly, args.Lx), 7)).cuda()
+    ref = model.predict(x, T, to_x=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            timeout=datetime.timedelta(seconds=120), device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        eng = model._engine(x)
+
+        def rollout(xx, oo):
+            eng.rollout(xx, T, to_x=True, out=oo)
+        r = parallel.EndGatherRollout(rollout, (args.in_channels, args.Ly, args.Lx), B, T, x.device, gather=True,
+                                      collective_at_world1=True)
+        r.run(x)
+        torch.cuda.synchronize()
+        r.finish_timing()
+        full = r.assemble()
+        assert full.data_ptr() != r.out.data_ptr() and tuple(full.shape) == (B, T, args.in_channels, args.Ly, args.Lx)
+        assert torch.equal(full, r.out) and torch.equal(full, ref)
+        assert len(r.exposed_ms) == 1 and r.exposed_ms[0] >= 0.0
+        maps = open("/proc/self/maps").read()
+        assert "librccl" in maps or "libnccl" in maps or "libtorch_hip" in maps
+    finally:
+        dist.destroy_process_group()
 
 
 def test_batch_shard_equivalence_and_b1():

@@ -62,6 +62,8 @@ from lns_amd import _lib
 import gpu_checks as gc
 L = _lib.lib()
 VARIANT = int(os.environ.get("CONV_VARIANT", "11"))      # 11 = f16x2 3x3 kernel (lns_kernels.h ConvVariant)
+# CONV_LAYOUT=256 (0x100): x is OCT8, 512 (0x200): y + residual are, 768: both (timing only: the buffers keep their sizes)
+LAYOUT = int(os.environ.get("CONV_LAYOUT", "0"))
 out = {}
 for name in which:
     c = cases[name]
@@ -78,7 +80,7 @@ for name in which:
     res = torch.randn(B, Cout, Hv, Wv, device="cuda") if c.get("res") else None
     def run():
         rc = L.lns_op_conv2d(x.data_ptr(), B, Cin, H, W, Hv, Wv, gc._hp(w), gc._hp(bias), Cout, k, 1, dil, p, p, p, p, 1, 1,
-                             ss.data_ptr() if c.get("ss", True) else None, c["act"], c.get("act_out", 0), res.data_ptr() if res is not None else None, None, y.data_ptr(), c.get("v", VARIANT if k == 3 else 7), None, None)
+                             ss.data_ptr() if c.get("ss", True) else None, c["act"], c.get("act_out", 0), res.data_ptr() if res is not None else None, None, y.data_ptr(), c.get("v", VARIANT if k == 3 else 7) | (LAYOUT if (k == 3 and Cin % 8 == 0 and Cout % 8 == 0) else 0), None, None)
         assert rc == 0
     for _ in range(NREP):
         run()

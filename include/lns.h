@@ -138,6 +138,9 @@ int lns_finalize_weights(lns_engine* e, int device);
  *   "decode_streams"  decode streams of the overlapped rollout (1..4)
  *   "overlap"         1: latent chain on a side stream, decodes round-robin on the decode streams; 0: one stream
  *   "prop_priority"   1: the side stream of the latent chain is created with the highest stream priority
+ *   "fa_chunk_mb"     FABlock2D: in_proj -> sandwich -> to_out are issued per group of samples whose 512-plane tensor is at
+ *                     most this many MB (it then stays in the 256 MB Infinity Cache between the three kernels instead of going
+ *                     to HBM three times); 0 = whole batch per launch.  Cached plans are rebuilt.  Default: LNS_FA_CHUNK_MB
  *   "track_nonfinite" 1: lns_check_finite also remembers the plan runs whose amax record has been reused since (the
  *                     earlier steps / decode groups of a rollout): one extra one-block launch per plan run (default 0)
  * Defaults come from LNS_DECODE_GROUP / LNS_DECODE_STREAMS / LNS_NO_OVERLAP / LNS_PROP_PRIORITY at lns_create().

@@ -472,6 +472,12 @@ struct Planner {
                     op.gn_geom = GnTileGeom{c.tiles_x, c.bw_log2, x.H, x.W, c.ks == 1 ? 1 : 0};
                     prod->conv.stat_count = -1;
                 }
+                // a batch-chunked producer: every chunk's launch leaves the partials of its own samples
+                if (prod->chunk_group > 0)
+                    for (Op& o : plan->ops)
+                        if (o.type == OP_CONV && o.chunk_group == prod->chunk_group) {
+                            o.conv.stat_part = prod->conv.stat_part; o.conv.stat_count = prod->conv.stat_count;
+                        }
                 op.bytes = 2.0 * B * tiles * x.C * 8;
                 lazy_ops.push_back(op);
                 if (foldable) { x.gn_lazy = li; return; }
@@ -743,6 +749,40 @@ struct Planner {
         return const_floats(cs);
     }
 
+    // FABlock2D's three passes over the 512-plane tensor (in_proj writes it, the sandwich rewrites it in place, to_out reads
+    // it: 537 MB at 64 x 64, B = 64 -- twice the Infinity Cache, so every pass goes to HBM) are re-issued per GROUP OF SAMPLES
+    // small enough for the group's slice to stay in the cache from one kernel to the next: [in_proj, sandwich, to_out](chunk 0),
+    // [...](chunk 1), ...  The ops in between (to_in, pooling, reducers, low-rank kernels) do not depend on in_proj and keep
+    // their place; per-sample arithmetic is untouched (ConvArgs::b0), so the bits do not change.
+    int next_chunk_group = 1;
+    int fa_chunk_samples(size_t bytes_per_sample) const {          // 0: no chunking
+        const long cap = (long)e->opt_fa_chunk_mb << 20;
+        if (cap <= 0 || (long)bytes_per_sample * B <= cap) return 0;
+        const int chunk = (int)std::max<long>(1, cap / (long)bytes_per_sample);
+        return chunk >= B ? 0 : chunk;
+    }
+    void chunk_fa_chain(size_t inproj_at, size_t sandwich_at, size_t toout_at, size_t bytes_per_sample) {
+        const int chunk = fa_chunk_samples(bytes_per_sample);
+        if (!chunk) return;
+        const Op a = plan->ops[inproj_at], s = plan->ops[sandwich_at], o = plan->ops[toout_at];
+        if (a.type != OP_CONV || s.type != OP_FASAND || o.type != OP_CONV || !(inproj_at < sandwich_at && sandwich_at < toout_at))
+            throw std::runtime_error("chunk_fa_chain: unexpected op order");
+        plan->ops.erase(plan->ops.begin() + toout_at);
+        plan->ops.erase(plan->ops.begin() + sandwich_at);
+        plan->ops.erase(plan->ops.begin() + inproj_at);
+        const int ga = next_chunk_group++, go = next_chunk_group++;
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = std::min(chunk, B - b0);
+            const double share = (double)nb / B;
+            Op ca = a, cs = s, co = o;
+            ca.conv.b0 = b0; ca.conv.B = nb; ca.chunk_group = ga;
+            cs.fs.b0 = b0; cs.fs.B = nb;
+            co.conv.b0 = b0; co.conv.B = nb; co.chunk_group = go;
+            for (Op* c : {&ca, &cs, &co}) { c->flops *= share; c->bytes *= share; c->mfma_flops *= share; }
+            plan->ops.push_back(ca); plan->ops.push_back(cs); plan->ops.push_back(co);
+        }
+    }
+
     TRef lower_fa(const Layer& l, TRef x, bool raw_out) {
         if (x.pending()) throw std::runtime_error("FABlock2D input must be materialised");
         const int C = x.C, H = x.H, W = x.W, heads = l.heads, dh = l.dim_head, lat = l.fa_lat, DK = l.fa_dk;
@@ -751,8 +791,13 @@ struct Planner {
         // in_proj records max |u| per sample: the sandwich's f16x2 form scales its planes by it (to_in's consumer, the
         // pooling, needs none)
         TRef uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj", -1, true);
+        const size_t inproj_at = plan->ops.size() - 1;
         TRef v = conv_same1(xin, l.toin, ACT_NONE, nullptr, nullptr, l.name + ".to_in", -1, false);
-        free_t(xin);
+        // (chunked: in_proj is re-issued AFTER the pooling / reducer / low-rank ops, so the GroupNorm table it reads must
+        //  outlive their allocations)
+        const bool fused_out = getenv("LNS_FA_NO_FUSE_TO_OUT") == nullptr && can_fuse_1x1(e->packs[l.out1], e->packs[l.out3]);
+        const bool will_chunk = fused_out && fa_chunk_samples((size_t)heads * dh * H * W * 4) > 0;
+        if (!will_chunk) free_t(xin);
         // axis pooling
         const size_t mx_off = arena.alloc((size_t)B * H * C * 4), my_off = arena.alloc((size_t)B * W * C * 4);
         {
@@ -850,7 +895,9 @@ struct Planner {
             }
             plan->ops.push_back(op);
         }
-        arena.release(kx_off); arena.release(ky_off);
+        const size_t sandwich_at = plan->ops.size() - 1;
+        // (chunked: the sandwich of chunk i + 1 runs after to_out of chunk i, so Kx / Ky must outlive to_out's allocations)
+        if (!will_chunk) { arena.release(kx_off); arena.release(ky_off); }
         // InstanceNorm output (biased variance over H*W values): |y| <= sqrt(H*W - 1)
         uphi.amax = 0; uphi.amax_const = sqrtf((float)(H * W));
         TRef out;
@@ -859,6 +906,10 @@ struct Planner {
             // to_out.1 (512 -> 64, GELU) and to_out.3 (64 -> 64) + skip in ONE kernel
             out = conv_same1(uphi, l.out1, ACT_GELU, &x, nullptr, l.name + ".to_out.1+3", l.out3, raw_out);
             free_t(uphi);
+            if (will_chunk) {
+                chunk_fa_chain(inproj_at, sandwich_at, plan->ops.size() - 1, (size_t)heads * dh * H * W * 4);
+                free_t(xin); arena.release(kx_off); arena.release(ky_off);
+            }
         } else {
             TRef t1 = conv_same1(uphi, l.out1, ACT_GELU, nullptr, nullptr, l.name + ".to_out.1");
             free_t(uphi);
@@ -1547,6 +1598,18 @@ struct Runner {
                 e->err = fmt("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(rc));
                 return LNS_EHIP;
             }
+            {   // LNS_DEBUG_SYNC=1 (diagnosis of a device fault): name every launch on stderr and wait for it, so that the last
+                // line printed names the kernel that faulted
+                static const bool dbg_sync = getenv("LNS_DEBUG_SYNC") != nullptr;
+                if (dbg_sync && op.type != OP_TRACE) {
+                    fprintf(stderr, "[lns] %s (plan B=%d, chunk b0=%d nb=%d)\n", op.name.c_str(), plan.B,
+                            op.type == OP_CONV ? op.conv.b0 : (op.type == OP_FASAND ? op.fs.b0 : 0),
+                            op.type == OP_CONV ? op.conv.B : (op.type == OP_FASAND ? op.fs.B : plan.B));
+                    fflush(stderr);
+                    const hipError_t se = hipStreamSynchronize(stream);
+                    if (se != hipSuccess) { e->err = fmt("%s: %s", op.name.c_str(), hipGetErrorString(se)); return LNS_EHIP; }
+                }
+            }
             if (e->timing_on && op.type != OP_TRACE) {
                 HIPCHK(e, hipEventRecord(ev.b, stream));
                 evs.push_back(ev);
@@ -1691,6 +1754,7 @@ int lns_create(const lns_config* cfg, lns_engine** out) {
     if (const char* v = getenv("LNS_DECODE_STREAMS")) e->opt_decode_streams = atoi(v);
     if (getenv("LNS_NO_OVERLAP")) e->opt_overlap = 0;
     if (getenv("LNS_PROP_PRIORITY")) e->opt_prop_priority = 1;
+    if (const char* v = getenv("LNS_FA_CHUNK_MB")) e->opt_fa_chunk_mb = atoi(v);
     e->cfg.ae_prefix[sizeof(e->cfg.ae_prefix) - 1] = 0;
     e->cfg.prop_prefix[sizeof(e->cfg.prop_prefix) - 1] = 0;
     try {
@@ -1760,6 +1824,17 @@ int lns_set_option(lns_engine* e, const char* name, long value) {
     else if (n == "decode_streams") { if (value < 1 || value > NDEC) return LNS_EINVAL; e->opt_decode_streams = (int)value; }
     else if (n == "overlap") e->opt_overlap = value != 0;
     else if (n == "track_nonfinite") e->opt_track_nonfinite = value != 0;
+    else if (n == "fa_chunk_mb") {
+        if (value < 0 || value > 4096) return LNS_EINVAL;
+        if (e->opt_fa_chunk_mb != (int)value) {         // a planning rule of the decoder / encoder: cached plans are rebuilt
+            DeviceGuard dg(e);
+            for (auto* m : {&e->enc_plans, &e->dec_plans}) {
+                for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
+                m->clear();
+            }
+        }
+        e->opt_fa_chunk_mb = (int)value;
+    }
     else if (n == "prop_priority") {
         if (e->opt_prop_priority != (value != 0)) { DeviceGuard dg(e); release_overlap_objects(e); }   // recreated with the new priority
         e->opt_prop_priority = value != 0;

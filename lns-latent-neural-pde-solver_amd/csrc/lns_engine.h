@@ -87,6 +87,7 @@ struct Op {
     // ("f16x2 ...": v_mfma_f32_32x32x16_f16, "fp32 ...": v_mfma_f32_32x32x2_f32, others: no matrix work booked)
     double mfma_flops = 0;
     const char* form = "";
+    int chunk_group = 0;      // > 0: one of several batch-chunked launches of the same layer (same id: same layer)
     int variant = 0;
     ConvArgs conv;
     GnStatsArgs gn;
@@ -158,6 +159,10 @@ struct lns_engine {
     int opt_decode_streams = 3;
     int opt_overlap = 1;           // propagator / decode streams; 0 = everything on the caller's stream
     int opt_prop_priority = 0;     // 1: the propagator's side stream is created with the highest priority
+    // FABlock2D: in_proj -> sandwich -> to_out run per group of samples whose 512-plane tensor is at most this many MB, so
+    // that it is still in the Infinity Cache (256 MB, shared by the streams of the overlapped rollout) when the next kernel
+    // reads it; 0 = whole batch per launch.  Scheduling only: the bits do not change.
+    int opt_fa_chunk_mb = 0;
     // what the last top-level call ran, for lns_check_finite: (plan kind, plan key, arena offset inside the caller's
     // workspace) -- no pointers into the plan caches or the workspace, which the caller may drop at any time -- plus
     // the workspace and batch of that call.  Cleared whenever plans are dropped.

@@ -95,6 +95,10 @@ struct ConvArgs {
     // conv <-> conv intermediates (C % 8 == 0; x, z, y and everything the plane-wise kernels read stay NCHW).
     // x_oct: the input is OCT8 (f16x2 3x3 kernels, split-operand 1x1 kernels); y_oct: the output AND the residual are.
     int x_oct, y_oct;
+    // batch-chunked launches (FABlock in_proj -> sandwich -> to_out per group of samples, so that the 512-plane tensor of a
+    // chunk is still in the 256 MB Infinity Cache when the next kernel reads it): the launch covers samples b0 .. b0 + B - 1
+    // of every per-sample array (blockIdx.y counts from b0)
+    int b0;
 #ifdef LNS_TS
     long long* dbg_ts;     // diagnostic build only: [blocks][8] phase timestamps (100 MHz wall clock) + hardware ids
 #endif
@@ -228,6 +232,7 @@ struct FaSandwichArgs {
     int B, heads, C, H, W; float eps; int instnorm; float* out;
     const unsigned* amax_u;            // [B][LNS_AMAX_SUB] max |u| per sample (bit patterns) or null: enables the f16x2 form
     int b_rev;                         // f16x2 form: walk the samples in reverse launch order (scheduling only)
+    int b0;                            // batch-chunked launch: samples b0 .. b0 + B - 1 (ConvArgs::b0)
 };
 hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s);
 size_t fa_sandwich_lds_bytes(int H, int W);

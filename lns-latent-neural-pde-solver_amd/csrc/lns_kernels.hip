@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (MT * NT >= 8 ? 1 : 2)) void conv_m
     const int l31 = lane & 31, kh = lane >> 5;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    const int b = blockIdx.y;
+    const int b = blockIdx.y + a.b0;
     int bid = blockIdx.x;
     const int ct = bid % a.cout_tiles;
     bid /= a.cout_tiles;
@@ -790,7 +790,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, size_t lds, hipStream_t s) {
 hipError_t launch_conv(int variant, const ConvArgs& a, hipStream_t s) {
     // OCT8 tensors: inputs of the f16x2 3x3 kernels, outputs of the kernels with the shared split-operand epilogue
     if (a.x_oct && !(cv_is_f16x2_3x3(variant) && !cv_is_pc(variant))) return hipErrorInvalidValue;
-    if (a.y_oct && !((cv_is_split_3x3(variant) && !cv_is_pc(variant)) || variant == CV_B1)) return hipErrorInvalidValue;
+    if (a.y_oct && !((cv_is_split_3x3(variant) && !cv_is_pc(variant)) || (variant == CV_B1 && a.ct_per_block == 0))) return hipErrorInvalidValue;
     if (cv_is_pc(variant)) return launch_conv_pc(variant == CV_P256 ? 2 : 1, a, s);
     if (cv_is_split_3x3(variant)) return launch_conv_bf16x3(variant, a, s);
     if (variant == CV_B1) return launch_conv1_bf16x3(a, s);
@@ -900,7 +900,10 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 // pix[nt]: flat output pixel of this lane in pixel tile nt, or -1.
 // addv: LDS vector [TM] of (bias + per-sample add) of this cout tile, staged in the prologue so that the epilogue
 // does not start with a round trip to L2 (null: read bias / badd from global memory here).
-template <int NT, bool FUSE2, int MT = 2, bool STATS = true>
+// OCT: the OCT8 output / residual paths (ConvArgs::y_oct) are compiled in.  The input-stationary 1x1 form (always a planar
+// output: FABlock in_proj feeds the plane-wise sandwich) is at its register budget and leaves them out -- with them the same
+// kernel measured 56 instead of 35 us per launch (same-box A/B, gpurun_out/ab_r03).
+template <int NT, bool FUSE2, int MT = 2, bool STATS = true, bool OCT = true>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
                                                float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1, long long* ets = nullptr,
@@ -933,7 +936,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     // epilogue arithmetic instead of one round trip per stored element (y may alias nothing, but the compiler
     // cannot know and would not move a load above an earlier store)
     float rv[MT][NT][16];
-    if (rb && a.y_oct) {
+    if (OCT && rb && a.y_oct) {
         // OCT8 residual ([Cout/8][HWo][8], planner: Cout % 8 == 0, tensor < 2 GB): the lane's four consecutive couts of
         // register group g are 16 contiguous bytes; octet row in the VGPR offset so that the range check masks a ragged
         // cout tile, a lane without a pixel starts at 2^31
@@ -1136,7 +1139,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
 #else
     constexpr bool kFastStore = true;
 #endif
-    if (a.y_oct) {
+    if (OCT && a.y_oct) {
         // OCT8 output: one 16-byte store per register group (4 per 32-cout block) instead of 16 dword stores; the hardware
         // range check drops lanes without a pixel (offset 2^31) and octet rows past Cout (ragged cout tile)
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)ybytes, 0x00020000);
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y + a.b0;
     int bid = blockIdx.x;
     int ct, phase = 0;
     if (UP2) {
@@ -1774,7 +1777,7 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y + a.b0;
     int bid = blockIdx.x;
     const int ct = bid % a.cout_tiles;
     const int tx = bid / a.cout_tiles;
@@ -2023,7 +2026,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y + a.b0;
     const int nchunk = (a.cout_tiles + a.ct_per_block - 1) / a.ct_per_block;
     const int chunk = blockIdx.x % nchunk, tx = blockIdx.x / nchunk;
     const int ct0 = chunk * a.ct_per_block;
@@ -2198,7 +2201,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
         }
         __syncthreads();
         if (++st == nstage) {
-            convb_epilogue<NT, false, MT, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, xinv, am);
+            convb_epilogue<NT, false, MT, false, false>(a, acc_hi, acc_lo, pix, b, ct0 + ctl, kh, l31, tid, smem, xinv, am);
             st = 0;
             ++ctl;
         }
@@ -2549,7 +2552,7 @@ hipError_t launch_conv_w8(const ConvArgs&, hipStream_t) { return hipErrorInvalid
 __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
     __shared__ float wsm[4 * 512];          // [co][c]
     __shared__ float2 ssm[512];             // (scale, shift) per channel
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, b = blockIdx.y + a.b0;
     const int HW = a.Hin * a.Win, C = a.Cin, CO = a.Cout;
     const bool has_ss = a.ss != nullptr;
     for (int i = tid; i < CO * C; i += 256) {                     // fp32 pack [tap 1][Cin_pad][Cout_pad]
@@ -3727,7 +3730,7 @@ __global__ __launch_bounds__(256, (HT * WT >= 6 || (HT * WT >= 4 && !VEC) ? 1 : 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int H = a.H, W = a.W, C = a.C;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.y, b = blockIdx.z + a.b0;
     const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
     const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
     // staged with all loads of a thread in flight at once (a plain copy loop keeps one outstanding)
@@ -3922,7 +3925,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fa_sandwich_b_kernel(FaSandwichAr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int H = a.H, W = a.W, C = a.C;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.y, b = blockIdx.z + a.b0;
     const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
     const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
     {   // Kx (column-permuted) and Ky, split, all loads of a thread in flight at once
@@ -4177,7 +4180,7 @@ __global__ __launch_bounds__(256, (WT <= 2 && (VEC || HT * WT < 4) ? 2 : 1)) voi
     const int H = a.H, W = a.W, C = a.C;
     // samples in REVERSE launch order (a.b_rev): the producer (in_proj) wrote sample B-1 last and the consumer (to_out) reads
     // sample 0 first, so both hand-overs of the 537 MB tensor start on the end that is still in the Infinity Cache
-    const int h = blockIdx.y, b = a.b_rev ? a.B - 1 - (int)blockIdx.z : (int)blockIdx.z;
+    const int h = blockIdx.y, b = a.b0 + (a.b_rev ? a.B - 1 - (int)blockIdx.z : (int)blockIdx.z);
     const float* kxg = a.kx + ((long)b * a.heads + h) * H * H;
     const float* kyg = a.ky + ((long)b * a.heads + h) * W * W;
     float s_p, i_p, s_kx, i_kx, s_ky, i_ky, s_u, i_u;       // scales and their inverses (powers of two)

@@ -167,7 +167,7 @@ class Engine:
 
     def set_option(self, name, value):
         """Scheduling options of the rollout (include/lns.h lns_set_option): decode_group, decode_streams, overlap,
-        prop_priority, track_nonfinite.  Results never depend on them."""
+        prop_priority, track_nonfinite, fa_chunk_mb.  Results never depend on them."""
         self._check(self._L.lns_set_option(self._h, name.encode(), int(value)), "lns_set_option")
         self._ws.clear()                      # the workspace size depends on the options
 
@@ -404,7 +404,10 @@ class Engine:
             self._check(self._L.lns_timing_info(self._h, i, name, len(name), ctypes.byref(ms), ctypes.byref(n),
                                                 ctypes.byref(fl), ctypes.byref(by)), "lns_timing_info")
             mf = ctypes.c_double()
-            self._check(self._L.lns_timing_mfma_flops(self._h, i, ctypes.byref(mf)), "lns_timing_mfma_flops")
+            try:
+                self._check(self._L.lns_timing_mfma_flops(self._h, i, ctypes.byref(mf)), "lns_timing_mfma_flops")
+            except _lib.LnsLibraryError:      # an earlier round's build under LNS_HIP_LIB (A/B runs): no executed-FLOP records
+                pass
             if n.value:
                 out[name.value.decode()] = dict(ms=ms.value, launches=int(n.value), flops=fl.value, bytes=by.value,
                                                 mfma_flops=mf.value)

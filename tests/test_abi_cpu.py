@@ -176,6 +176,7 @@ def test_set_option_validates_names_and_ranges():
     e.set_option("decode_group", 4)
     e.set_option("decode_streams", 2)
     e.set_option("overlap", 0)
-    for bad in (("decode_group", 99), ("decode_streams", 0), ("no_such_option", 1)):
+    e.set_option("fa_chunk_mb", 128)
+    for bad in (("decode_group", 99), ("decode_streams", 0), ("no_such_option", 1), ("fa_chunk_mb", -1)):
         with pytest.raises(_lib.LnsError):
             e.set_option(*bad)

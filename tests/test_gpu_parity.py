@@ -592,8 +592,11 @@ def test_overlapped_rollout_equals_single_stream():
     eng.timing_enable(False)
     # scheduling options never change a bit: steps decoded per launch set (batch 64 * k, ragged last group: 6 = 4 + 2),
     # number of decode streams, stream priority of the latent chain, single stream
+    # ... and the FABlock's in_proj -> sandwich -> to_out chain issued per group of samples (fa_chunk_mb: 537 MB at 64 x 64 -> 16
+    # samples per chunk at 128 MB; 60 MB: 7 samples, ragged last chunk, and the 32 x 32 block is chunked too)
     for opts in (dict(decode_group=1), dict(decode_group=4), dict(decode_group=4, decode_streams=2, prop_priority=1),
-                 dict(decode_group=3, overlap=0), dict(decode_group=0), dict(decode_group=1, decode_streams=3, overlap=1, prop_priority=0)):
+                 dict(decode_group=3, overlap=0), dict(decode_group=0), dict(decode_group=1, decode_streams=3, overlap=1, prop_priority=0),
+                 dict(fa_chunk_mb=128), dict(fa_chunk_mb=60, decode_group=2), dict(fa_chunk_mb=60, overlap=0), dict(fa_chunk_mb=0, overlap=1)):
         for k, v in opts.items():
             eng.set_option(k, v)
         for _ in range(2):

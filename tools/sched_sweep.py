@@ -17,7 +17,10 @@ R = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 GROUPS = [int(v) for v in os.environ.get("SWEEP_GROUPS", "1,2,4").split(",")]
 STREAMS = [int(v) for v in os.environ.get("SWEEP_STREAMS", "2,3").split(",")]
 PRIOS = [int(v) for v in os.environ.get("SWEEP_PRIO", "0").split(",")]
-ARMS = [dict(decode_group=g, decode_streams=s, prop_priority=p) for g in GROUPS for s in STREAMS for p in PRIOS]
+CHUNKS = [int(v) for v in os.environ.get("SWEEP_FA_CHUNK_MB", "0").split(",")]      # FABlock chain per group of samples (fa_chunk_mb)
+ARMS = [dict(decode_group=g, decode_streams=s, prop_priority=p, fa_chunk_mb=c) for g in GROUPS for s in STREAMS for p in PRIOS for c in CHUNKS]
+if os.environ.get("SWEEP_SERIAL"):
+    ARMS = [dict(a, overlap=0) for a in ARMS]
 args, model, sd = bench.build_model(preset, torch.device("cuda", 0))
 x = torch.from_numpy(filler.normal("x", (B, args.in_channels, args.Ly, args.Lx), 5)).cuda()
 param = torch.from_numpy(filler.uniform01("p", B, 5).astype("float32")).cuda() if args.family == "twophase_cond" else None
@@ -29,6 +32,7 @@ for r in range(R + 1):
     for i, arm in enumerate(ARMS):
         for k, v in arm.items():
             eng.set_option(k, v)
+        print("round %d arm %s" % (r, arm), file=sys.stderr, flush=True)
         eng.rollout(x, T, param=param, to_x=True, out=out)        # (first call after an option change allocates)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -112,7 +112,8 @@ struct ConvGeom { int variant, bw_log2, tiles_x, tiles_y, cout_tiles, PH, PW, Ho
 
 static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, int stride, int dil, const int* pad,
                           int kc_log2_pack, int Cout_pad, int force_variant, bool need_wgm1 = false,
-                          bool allow_bf16x3 = false, int Cin = 1 << 30, bool f16x2 = false, bool allow_thin = false) {
+                          bool allow_bf16x3 = false, int Cin = 1 << 30, bool f16x2 = false, bool allow_thin = false,
+                          int force_bw_log2 = -1 /* 3x3: only this tile width (the quad-phase upsampling conv wants 8 x 16 tiles) */) {
     g.Hout = (Hv + pad[0] + pad[1] - dil * (k - 1) - 1) / stride + 1;
     g.Wout = (Wv + pad[2] + pad[3] - dil * (k - 1) - 1) / stride + 1;
     if (g.Hout <= 0 || g.Wout <= 0) return false;
@@ -163,7 +164,7 @@ static bool conv_geometry(ConvGeom& g, int B, int Cout, int Hv, int Wv, int k, i
             for (int pi = 0; pi < 6; ++pi) {
                 const int lb = pref[pi];
                 const int BW = 1 << lb;
-                if (BW > vi.TN) continue;
+                if (BW > vi.TN || (force_bw_log2 >= 0 && lb != force_bw_log2)) continue;
                 const int BH = vi.TN / BW;
                 const long cost = (long)((g.Hout + BH - 1) / BH) * BH * ((g.Wout + BW - 1) / BW) * BW;
                 tmp.PH = (BH - 1) * stride + (k - 1) * dil + 1;
@@ -518,6 +519,26 @@ struct Planner {
                            pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok))
             throw std::runtime_error("no conv tiling for " + name);
         if (up2 && g.variant != CV_F64) throw std::runtime_error("phase form needs the f16x2 64-cout tiles: " + name);
+        // Round 4: the quad-phase form of the upsampling conv (conv3_up2q.inc: the patch staged once, four phases per block,
+        // two blocks per CU) wants 8 x 16 source tiles -- a 10 x 18 patch of 8 stages is what fits beside its weight ring in
+        // 80 KB.  MEASURED (profiles/r04_up2q_time.txt): the plain 64 -> 64 layer at 128^2 213.5 -> 197.6 us, but the layer the
+        // decoder runs -- the same conv with the fused 1x1 -- 271 -> 278 us (its epilogue spills 96 registers at two waves per
+        // SIMD) and the 64-channel UpSampleBlock conv 48.5 -> 49.0 us: rollout 34.6k -> 34.3k.  Opt-in (LNS_UP2_QUAD=1) in
+        // -DLNS_EXPERIMENTAL builds only; a per-layer rule (Cin_pad in {16, 32, 48, 64}, no residual, the tiling exists).
+        bool quad = false;
+        {
+            static const bool no_quad = getenv("LNS_UP2_QUAD") == nullptr || getenv("LNS_UP2_RESIDENT") != nullptr;
+            ConvGeom gq;
+            if (up2 && !no_quad && !res && pk.Cin_pad <= 64 && pk.Cin_pad % 16 == 0 &&
+                conv_geometry(gq, B, pk.cout, Hv, Wv, k, stride, dil, pad, pk.kc_log2, pk.Cout_pad, CV_F64, fuse_pack >= 0,
+                              pk.has_wb && in.bounded(), pk.cin, pk.f16, thin_ok, 4)) {
+                ConvArgs t;
+                memset(&t, 0, sizeof t);
+                t.ks = 3; t.stride = 1; t.dil = 1; t.up2 = 1; t.wb = &t; t.Cin_pad = pk.Cin_pad; t.PH = gq.PH; t.PW = gq.PW;
+                t.Cout = pk.cout; t.Hout = 2 * in.H; t.Wout = 2 * in.W;
+                if (convuq_fits(t)) { g = gq; quad = true; }
+            }
+        }
         // (thrown before anything is allocated or emitted: a caller may catch it and materialise the activation instead)
         if (in.act == ACT_GELU && ((g.variant != CV_F64 && g.variant != CV_F32) || up2 || fuse_pack >= 0))
             throw NoGeluPrologue("GELU prologue is only built into the f16x2 3x3 kernel: " + name);
@@ -612,6 +633,7 @@ struct Planner {
             // Kept as an opt-in variant (LNS_UP2_RESIDENT=1) with its parity tests.
             static const bool res = getenv("LNS_UP2_RESIDENT") != nullptr;
             if (res) { a.up2 = 2; if (!convur_fits(a)) a.up2 = 1; }
+            if (quad && convuq_fits(a)) a.up2 = 3;
         }
         op.flops = 2.0 * B * g.Hout * g.Wout * (double)pk.cout * pk.cin * k * k;
         op.bytes = 4.0 * B * ((double)in.C * in.H * in.W + (double)pk.cout * g.Hout * g.Wout * (res ? 2 : 1));
@@ -2254,7 +2276,8 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     const bool forced = tile_variant >= 0;
     if (w8) tile_variant = CV_F64;
     const bool up2r = tile_variant == 18;           // test code: ... its resident-patch form (conv3_up2r.inc)
-    const bool up2 = tile_variant == 17 || up2r;    // test code: f16x2 3x3 kernel, phase form of an exactly-2x nearest upsample
+    const bool up2q = tile_variant == 20;           // test code: ... its quad-phase form (conv3_up2q.inc)
+    const bool up2 = tile_variant == 17 || up2r || up2q;    // test code: f16x2 3x3 kernel, phase form of an exactly-2x nearest upsample
     if (up2) {
         if (ksize != 3 || stride != 1 || dilation != 1 || Hv != 2 * Hin || Wv != 2 * Win || pad_t != 1 || pad_b != 1 || pad_l != 1 || pad_r != 1) return LNS_EINVAL;
         tile_variant = CV_F64; Hv = Hin; Wv = Win;
@@ -2273,7 +2296,8 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     if (Wv <= 0) Wv = Win;
     const int pad[4] = {pad_t, pad_b, pad_l, pad_r};
     ConvGeom g;
-    if (!conv_geometry(g, B, Cout, Hv, Wv, ksize, stride, dilation, pad, pk.kc_log2, pk.Cout_pad, tile_variant)) return LNS_EINVAL;
+    if (!conv_geometry(g, B, Cout, Hv, Wv, ksize, stride, dilation, pad, pk.kc_log2, pk.Cout_pad, tile_variant, false, false, 1 << 30, false,
+                       false, up2q ? 4 : -1)) return LNS_EINVAL;
     const ConvVariantInfo vi = conv_variant_info(g.variant);
     const int BW = 1 << g.bw_log2, BH = vi.TN / BW;
     std::vector<int> rm, cm;
@@ -2339,6 +2363,10 @@ static int op_conv_prepare(OpConv& oc, const float* x, int B, int Cin, int Hin, 
     if (up2r) {
         a.up2 = 2;
         if (!convur_fits(a)) return LNS_EINVAL;
+    }
+    if (up2q) {
+        a.up2 = 3;
+        if (!convuq_fits(a)) return LNS_EINVAL;
     }
     a.w8 = w8 ? 1 : (forced ? -1 : 0);              // a forced tile variant means that kernel
     a.x_oct = (layout & 0x100) ? 1 : 0; a.y_oct = (layout & 0x200) ? 1 : 0;

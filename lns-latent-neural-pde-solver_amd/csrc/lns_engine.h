@@ -89,24 +89,26 @@ struct Op {
     const char* form = "";
     int chunk_group = 0;      // > 0: one of several batch-chunked launches of the same layer (same id: same layer)
     int variant = 0;
-    ConvArgs conv;
-    GnStatsArgs gn;
+    // (every argument block is zero-initialised: a field added to one of them -- e.g. the batch-chunk offset b0 -- must never
+    //  reach a launch as stack garbage from a site that fills the block member by member)
+    ConvArgs conv = {};
+    GnStatsArgs gn = {};
     const float* gn_tile_part = nullptr;   // GroupNorm fed by a convolution's per-tile partials (tagged pointer)
     int gn_tiles = 0;
     int gn_count = 0;           // pixels behind every tile partial (GN_TILE_PIXELS, or the plane of a ragged single tile);
     GnTileGeom gn_geom = {0, 0, 0, 0, 0};   // -1: ragged tiles of a larger plane, counts from gn_geom (unequal-count merge)
-    LnPeArgs ln;
-    AttnArgs at;
-    FaPoolArgs fp;
-    FaReducerArgs fr, fr2;     // fr2 / fl2: second axis of the merged two-axis launches
-    FaLrkArgs fl, fl2;
-    FaSandwichArgs fs;
-    CondBaseArgs cb;
-    CondBlockArgs ck;
-    ApplyArgs ap;
-    SpectralArgs sp;
-    FourierCombineArgs fc;
-    VecLinearArgs vl;
+    LnPeArgs ln = {};
+    AttnArgs at = {};
+    FaPoolArgs fp = {};
+    FaReducerArgs fr = {}, fr2 = {};     // fr2 / fl2: second axis of the merged two-axis launches
+    FaLrkArgs fl = {}, fl2 = {};
+    FaSandwichArgs fs = {};
+    CondBaseArgs cb = {};
+    CondBlockArgs ck = {};
+    ApplyArgs ap = {};
+    SpectralArgs sp = {};
+    FourierCombineArgs fc = {};
+    VecLinearArgs vl = {};
     // trace
     uint64_t t_ptr = 0; long t_bs = 0; int tC = 0, tH = 0, tW = 0;
 };

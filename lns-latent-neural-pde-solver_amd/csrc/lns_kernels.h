@@ -50,7 +50,8 @@ struct ConvArgs {
     // 1: `wb` holds the PHASE slabs of a 3x3 convolution applied to the 2x nearest-upsampled input (convu_pack_weight):
     // x is the SOURCE tensor, tiles / patch / maps are those of a plain pad-1 3x3 convolution of the source, and
     // Hout = 2 Hin, Wout = 2 Win; every block computes 128 source pixels of one of the four output phases (f16x2 kernel)
-    int up2;               // (2: the resident-patch form, conv3_up2r.inc -- one block per source tile walks the four phases)
+    int up2;               // (2: the resident-weights form, conv3_up2r.inc, experimental; 3: the quad-phase form, conv3_up2q.inc --
+                           //  one block per source tile stages the patch once and walks the four phases, two blocks per CU)
     // GroupNorm folded into this convolution's prologue (split-operand 3x3 / 1x1 kernels): instead of the finished
     // (scale, shift) table `ss`, the per-(sample, 128-pixel tile, channel) (mean, M2) partials the PRODUCER's epilogue left
     // ([B][gn_tiles][Cin][2], ConvArgs::stat_part of that launch) plus gamma / beta; every block of a sample merges them
@@ -143,6 +144,8 @@ bool convpc_fits(const ConvArgs& a, int nt);
 hipError_t launch_conv_pc(int nt, const ConvArgs& a, hipStream_t s);
 // host-side packing of one [Cout][Cin][3][3] weight (cout offset co0 inside the pack) into the bf16x3 slab layout
 size_t convb_weight_bytes(int Cout, int Cin_pad);
+bool convuq_fits(const ConvArgs& a);        // quad-phase form of the upsampling conv (ConvArgs::up2 == 3; a.up2 != 0 on entry)
+size_t convuq_lds_bytes(const ConvArgs& a);
 bool convur_fits(const ConvArgs& a);        // resident-patch form of the upsampling conv (ConvArgs::up2 == 2)
 size_t convur_lds_bytes(const ConvArgs& a);
 void convb_pack_weight(void* dst, const float* w, int co0, int cout, int cin, int Cin_pad);

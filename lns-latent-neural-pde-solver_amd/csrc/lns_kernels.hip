@@ -903,7 +903,10 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 // OCT: the OCT8 output / residual paths (ConvArgs::y_oct) are compiled in.  The input-stationary 1x1 form (always a planar
 // output: FABlock in_proj feeds the plane-wise sandwich) is at its register budget and leaves them out -- with them the same
 // kernel measured 56 instead of 35 us per launch (same-box A/B, gpurun_out/ab_r03).
-template <int NT, bool FUSE2, int MT = 2, bool STATS = true, bool OCT = true>
+// SHALF: the tile statistics go through the LDS scratch in two halves of 32 channels (17 KB instead of 34 KB; two more
+// barriers): the quad-phase upsampling conv (conv3_up2q.inc) keeps its whole split patch in LDS and has 18.5 KB of scratch.
+// NORES: the launch has no residual tensor (host-checked): the 32 registers of the residual tile are not reserved.
+template <int NT, bool FUSE2, int MT = 2, bool STATS = true, bool OCT = true, bool SHALF = false, bool NORES = false>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
                                                float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1, long long* ets = nullptr,
@@ -931,7 +934,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 acc[mt][nt][r] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r]) * a.unscale) * xinv;   // the other: no intermediate underflow
     const int HWo = a.Hout * a.Wout;
     float* yb = y_base(a, b);
-    const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+    const float* rb = (!NORES && a.res) ? a.res + (long)b * a.res_bs : nullptr;
     // residual tile: all loads issued here, branch-free (clamped addresses), so their latency hides behind the
     // epilogue arithmetic instead of one round trip per stored element (y may alias nothing, but the compiler
     // cannot know and would not move a load above an earlier store)
@@ -1159,7 +1162,8 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                         if (rb) v += rv[mt][nt][4 * g + j];
                         t[j] = __float_as_uint(v);
                         am = max(am, vr < nb ? abs_bits(v) : 0u);
-                        if (stats) sb[(mt * 32 + drow(4 * g + j, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
+                        if (SHALF) acc[mt][nt][4 * g + j] = v;
+                        else if (stats) sb[(mt * 32 + drow(4 * g + j, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(t, yr, (int)vr, 0, 0);
                 }
@@ -1187,7 +1191,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     am = max(am, abs_bits(v));
                 }
         }
-        if (stats) {
+        if (stats && !SHALF) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1220,7 +1224,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     const float v = acc[mt][nt][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)vr, 0, 0);
                     am = max(am, vr < nb ? abs_bits(v) : 0u);
-                    if (stats) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
+                    if (stats && !SHALF) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
                 }
         }
     } else
@@ -1240,20 +1244,32 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                     if (rb) v += rv[mt][nt][r];
                     yp[ro] = v;
                     am = max(am, abs_bits(v));
-                    if (stats) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;
+                    if (SHALF) acc[mt][nt][r] = v;
+                    else if (stats) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;
                 }
             }
         }
     }
     LNS_ETS(4)
-    if (stats) {
+    constexpr int SROWS = SHALF ? 32 : TM;          // channel rows of the scratch tile per pass
+    if (stats)
+    for (int hf = 0; hf < (SHALF ? MT : 1); ++hf) {
+        if (SHALF) {      // this half's 32 channels of the (final) register tile -> scratch
+            if (hf) __syncthreads();                 // the previous half has been read
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt == hf) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sb[drow(r, kh) * SROW + (tid >> 6) * 33 + l31] = acc[mt][0][r];
+                }
+        }
         // ragged single tile (ConvArgs::stat_count valid pixels): which of a wave's 32 pixels exist, one word per wave
-        unsigned* smask = reinterpret_cast<unsigned*>(sb + 64 * SROW);
+        unsigned* smask = reinterpret_cast<unsigned*>(sb + SROWS * SROW);
         const unsigned long long have = __builtin_amdgcn_ballot_w64(pix[0] >= 0);     // (all lanes: lanes 0..31 are the wave's pixels)
         if (a.stat_count && (tid & 63) == 0) smask[tid >> 6] = (unsigned)have;
         __syncthreads();
         const int c = tid >> 2, q = tid & 3;
-        if (c < TM) {            // (whole waves: 64-cout tiles keep all four busy, 32-cout tiles two)
+        if (c < SROWS) {         // (whole waves: 64-cout tiles keep all four busy, 32-cout tiles / half passes two)
         const float* row = sb + c * SROW + q * 33;
         float v[32];
 #pragma unroll
@@ -1309,7 +1325,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
             mean = 0.5f * (mean + mo);
         }
         }
-        const int co = ct * TM + c;
+        const int co = ct * TM + (SHALF ? hf * 32 : 0) + c;
         if (q == 0 && co < a.Cout) {
             const int tile = sp_tile >= 0 ? sp_tile : (int)blockIdx.x / a.cout_tiles, ntiles = a.tiles_x * a.tiles_y * tile_mult;
             float* pp = a.stat_part + (((long)b * ntiles + tile) * a.Cout + co) * 2;
@@ -2440,6 +2456,7 @@ void convb1_pack_weight(void* dst, const float* w, int co0, int cout, int cin, i
 }
 
 hipError_t launch_conv_up2r(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_up2q(const ConvArgs& a, hipStream_t s);
 hipError_t launch_conv_w8(const ConvArgs& a, hipStream_t s);
 bool convw8_fits(const ConvArgs& a);
 hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
@@ -2454,7 +2471,8 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv3_bf16x3_kernel<2, 2, false, 2, 2>), grid, dim3(256), lds, s, a);
         return hipGetLastError();
     }
-    if (a.x_oct && (a.up2 == 2 || a.w8 == 1)) return hipErrorInvalidValue;       // (the experimental forms read planar tensors)
+    if (a.x_oct && (a.up2 >= 2 || a.w8 == 1)) return hipErrorInvalidValue;       // (these forms read planar tensors)
+    if (variant == CV_F64 && a.up2 == 3) return launch_conv_up2q(a, s);     // all four phases per block, two blocks per CU (conv3_up2q.inc)
     if (variant == CV_F64 && a.up2 == 2) return launch_conv_up2r(a, s);     // ... with the source patch resident in LDS (conv3_up2r.inc)
     // OCT8 tensors (ConvArgs::x_oct / y_oct): whole octets, 32-bit byte offsets
     if ((a.x_oct && ((a.Cin & 7) || (long)a.Cin * a.Hin * a.Win * 4 >= (1L << 31) || !cv_is_f16x2_3x3(variant) || variant == CV_F256)) ||
@@ -2521,17 +2539,22 @@ hipError_t launch_conv_bf16x3(int variant, const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Three kernel forms that were built, proven bit-identical to the shipped kernels and MEASURED SLOWER:
-// producer / consumer waves (conv3_pc.inc), the resident-patch upsampling conv (conv3_up2r.inc), the 8-wave small-launch
-// form (conv3_w8.inc).  They are kept as source with their parity tests but only compiled with -DLNS_EXPERIMENTAL
-// (make DIAGFLAGS=-DLNS_EXPERIMENTAL); the shipped library carries only kernels the planner uses.
+// Four kernel forms that were built, proven bit-identical to the shipped kernels and MEASURED SLOWER or neutral (DESIGN.md
+// sections 6d, 6e): producer / consumer waves (conv3_pc.inc), the resident-weights upsampling conv (conv3_up2r.inc), the 8-wave
+// small-launch form (conv3_w8.inc), the quad-phase upsampling conv (conv3_up2q.inc, round 4: -7 % on the plain 64 -> 64 layer,
+// +3 % on the one the decoder actually runs, the fused 3x3 + 1x1).  They are kept as source with their parity tests but only
+// compiled with -DLNS_EXPERIMENTAL (make DIAGFLAGS=-DLNS_EXPERIMENTAL); the shipped library carries only kernels the planner uses.
 #ifdef LNS_EXPERIMENTAL
 #include "conv3_pc.inc"
 #include "conv3_up2r.inc"
+#include "conv3_up2q.inc"
 #include "conv3_w8.inc"
 bool build_has_experimental() { return true; }
 #else
 bool build_has_experimental() { return false; }
+size_t convuq_lds_bytes(const ConvArgs&) { return 0; }
+bool convuq_fits(const ConvArgs&) { return false; }
+hipError_t launch_conv_up2q(const ConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
 size_t convpc_lds_bytes(const ConvArgs&, int) { return 0; }
 bool convpc_geom_fits(const ConvArgs&, int) { return false; }
 bool convpc_fits(const ConvArgs&, int) { return false; }
@@ -4918,6 +4941,8 @@ hipError_t init_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
 #ifdef LNS_EXPERIMENTAL
+    LNS_SET_LDS((conv3_up2q_kernel<true>))
+    LNS_SET_LDS((conv3_up2q_kernel<false>))
     LNS_SET_LDS(conv3_w8_kernel<1>)
     LNS_SET_LDS(conv3_w8_kernel<2>)
     LNS_SET_LDS((conv3_up2r_kernel<true>))

@@ -228,6 +228,14 @@ UP2R_CASES = [c for c in UP2_CASES if c["Cin"] <= 64] + [
     dict(B=1, Cin=64, Cout=128, H=16, W=32, up=(32, 64), mode=(0, 0), badd=True, act_out=2)]
 for _c in UP2R_CASES:
     CONV_CASES.append(dict(k=3, variant=18, **_c))
+# ... its quad-phase form (variant 20, conv3_up2q.inc: Cin_pad 16 .. 64; the patch staged once, four phases per block, the phase
+# weights streamed through an LDS ring, statistics scratch in halves)
+UP2Q_CASES = [c for c in UP2R_CASES if c["Cin"] in (16, 32, 48, 64) and not c.get("res")] + [
+    dict(B=2, Cin=16, Cout=64, H=8, W=16, up=(16, 32), mode=(1, 1), ss=True, act_in=1),
+    dict(B=3, Cin=48, Cout=72, H=21, W=13, up=(42, 26), mode=(0, 1), badd=True, act_out=1),
+    dict(B=2, Cin=32, Cout=128, H=12, W=24, up=(24, 48), mode=(0, 0), ss=True)]
+for _c in UP2Q_CASES:
+    CONV_CASES.append(dict(k=3, variant=20, **_c))
 # f16x2 3x3 kernel, 8-wave form for small launches (variant 19)
 for _c in [dict(B=2, Cin=128, Cout=128, H=16, W=16, ss=True, act_in=1, mode=(1, 1)), dict(B=2, Cin=128, Cout=128, H=7, W=15, ss=True, mode=(0, 0), badd=True),
            dict(B=2, Cin=40, Cout=100, H=21, W=37, ss=True, act_in=1, res=True, mode=(0, 0)), dict(B=1, Cin=64, Cout=64, H=16, W=16, dil=2, mode=(1, 1), act_out=2)]:

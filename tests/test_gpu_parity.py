@@ -28,7 +28,7 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-EXPERIMENTAL_VARIANTS = (15, 16, 18, 19)      # kernel forms only compiled with -DLNS_EXPERIMENTAL (csrc/conv3_{pc,up2r,w8}.inc)
+EXPERIMENTAL_VARIANTS = (15, 16, 18, 19, 20)  # kernel forms only compiled with -DLNS_EXPERIMENTAL (csrc/conv3_{pc,up2r,up2q,w8}.inc)
 
 
 def _experimental():
@@ -55,6 +55,15 @@ def test_conv_kernel(idx, case):
     import gpu_checks as gc
     if case.get("variant") in EXPERIMENTAL_VARIANTS and not _experimental():
         pytest.skip("variant %d is only compiled with -DLNS_EXPERIMENTAL (measured slower; DESIGN.md 6d)" % case["variant"])
+    if case.get("variant") == 20:
+        try:
+            err, _ = gc.conv_case(seed=idx, **case)
+        except AssertionError as ex:         # the quad-phase form refuses patches that do not fit its 80 KB (LNS_EINVAL): the
+            if "rc=-1" in str(ex):           # planner then keeps the per-phase form
+                pytest.skip("patch does not fit the quad-phase form's LDS budget")
+            raise
+        assert err < KERNEL_TOL, (case, err)
+        return
     err, _ = gc.conv_case(seed=idx, **case)
     assert err < KERNEL_TOL, (case, err)
 
@@ -112,6 +121,59 @@ def test_conv_oct8_layouts_same_bits():
         y0 = gc.conv_case(k=3, variant=17, seed=13, ret_y=True, **kw)[2]
         y1 = gc.conv_case(k=3, variant=17, seed=13, ret_y=True, xoct=True, yoct=True, **kw)[2]
         assert np.array_equal(y0, y1), kw
+
+
+def test_upsampling_conv_quad_phase_same_bits():
+    """The quad-phase form of the phase-decomposed upsampling conv (op-level variant 20, conv3_up2q.inc: one block stages the
+    split source patch of all channels once and walks the four output phases, streaming the phase weights through a two-slot
+    LDS ring; GroupNorm tile statistics through a half-size scratch) gives the bits of the per-phase form (17)."""
+    _need_gpu()
+    if not _experimental():
+        pytest.skip("conv3_up2q.inc is only compiled with -DLNS_EXPERIMENTAL (measured neutral to slower; DESIGN.md 6e)")
+    import gpu_checks as gc
+    import numpy as np
+    ran = 0
+    for kw in gc.UP2Q_CASES:
+        try:
+            y20 = gc.conv_case(k=3, variant=20, seed=9, ret_y=True, **kw)[2]
+        except AssertionError as ex:
+            if "rc=-1" in str(ex):           # patch beyond the form's LDS budget: refused, the planner keeps the per-phase form
+                continue
+            raise
+        y17 = gc.conv_case(k=3, variant=17, seed=9, ret_y=True, **kw)[2]
+        assert np.array_equal(y17, y20), kw
+        ran += 1
+    assert ran >= 5, ran
+
+
+def test_quad_phase_upsampling_conv_in_the_decoder(monkeypatch):
+    """The planner's rule (decoder layers behind a 2x nearest upsample with <= 64 input channels: the last layer with its fused
+    1x1 and GroupNorm tile statistics, the 64-channel UpSampleBlock) against the per-phase form (LNS_NO_UP2_QUAD=1, read when
+    the FIRST plan of a process is built: a child process runs that arm): the decoded fields agree to rounding."""
+    _need_gpu()
+    if not _experimental():
+        pytest.skip("conv3_up2q.inc is only compiled with -DLNS_EXPERIMENTAL (measured neutral to slower; DESIGN.md 6e)")
+    import subprocess
+    import sys
+    from helpers import ROOT
+    code = ("import sys, torch, numpy as np; sys.path[:0] = [%r, %r, %r]\n"
+            "import gpu_checks as gc\nfrom lns_amd import config, filler\n"
+            "args = config.preset('ns2d_128'); model, _ = gc.build_models(args, 1)\n"
+            "x = torch.from_numpy(filler.normal('xq', (3, args.in_channels, args.Ly, args.Lx), 5)).cuda()\n"
+            "y = model.predict(x, 2, to_x=True); torch.cuda.synchronize(); np.save(sys.argv[1], y.cpu().numpy())\n"
+            % (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')))
+    import tempfile
+    outs = []
+    for env_extra in ({"LNS_UP2_QUAD": "1"}, {}):
+        f = tempfile.mktemp(suffix=".npy")
+        env = dict(os.environ, **env_extra)
+        p = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        outs.append(np.load(f))
+        os.remove(f)
+    # (not bit for bit: the quad-phase form tiles the source 8 x 16 where the per-phase form tiles it 4 x 32, so the GroupNorm
+    #  tile statistics of the layer's output are merged from other partial sums -- a rounding-level difference, 1e-7)
+    assert np.isfinite(outs[0]).all() and rel_l2(outs[0], outs[1]) < 1e-6, rel_l2(outs[0], outs[1])
 
 
 def test_upsampling_conv_resident_patch_same_bits():

@@ -33,6 +33,7 @@ cases = {
     "lat_b256": dict(B=256, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0),
     "lat_d2": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, ss=True, act=0, dil=2),
     "up32": dict(B=64, Cin=128, Cout=128, H=16, W=16, k=3, up=(32, 32), ss=False, act=0),
+    "up64": dict(B=64, Cin=64, Cout=64, H=32, W=32, k=3, up=(64, 64), ss=False, act=0),          # the 64-channel UpSampleBlock conv
     "c32_64": dict(B=64, Cin=128, Cout=64, H=32, W=32, k=3, ss=True, act=1),
     "lat_tp": dict(B=32, Cin=128, Cout=128, H=7, W=15, k=3, ss=True, act=0),        # config 4's latent plane: one ragged tile
     "lat_tp_d4": dict(B=32, Cin=128, Cout=128, H=7, W=15, k=3, ss=True, act=0, dil=4),

@@ -1770,6 +1770,19 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 // A 1x1 conv has no tap reuse, so the fp32 -> 3 x bf16 split (VALU) is about as much work as the MFMAs;
 // it is interleaved with them the same way as in the 3x3 kernel.
 // ===========================================================================
+// LDS slot of pixel p inside an octet row of the 1x1 kernels' pixel image [split][octet][pixel][8 ch]: adjacent pairs of
+// slots are swapped in every other group of eight.  The staging threads own pixel PAIRS (8-byte global loads), so the eight
+// lanes of a ds_write_b128 group are 32 bytes apart and, unswizzled, lanes i and i + 4 fall on the same four banks (write
+// banking is (address / 4) mod 32): a two-way conflict on every patch write -- 24 - 30 % of the LDS-array cycles of these
+// kernels in profiles/r03_pmc.json.  With the swap the eight lanes cover all 32 banks; the fragment reads (16 consecutive
+// pixels per ds_read_b128 lane group, banking mod 64) stay conflict-free.  LNS_CONV1_NO_SWIZZLE: A/B build knob.
+__device__ __forceinline__ int conv1_slot(int p) {
+#ifdef LNS_CONV1_NO_SWIZZLE
+    return p;
+#else
+    return p ^ ((p >> 3) & 1);
+#endif
+}
 // split scheme of the 1x1 kernels: 2 = two fp16 terms of the scaled operand (f16x2, see the 3x3 kernel), 3 = three bf16 terms
 #define CONVB1_SPL 2
 // 1: the three products of the f16x2 scheme go into ONE fp32 accumulator per tile (an fp32 chain's accuracy; 32 fewer
@@ -1829,7 +1842,7 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
                                                                         (a.Cin_pad / KC) * CONVB1_SLAB_BYTES, 0x00020000);
     const int cin_m1 = a.Cin - 1, hw4 = HW * 4;
     const int aoff = (kh * TM + l31) * 16;                 // + (s*4 + 2j) * TM*16 + mt*32*16
-    const int boff = (kh * TN + wn * 32 + l31) * 16;       // + (s*4 + 2j) * TN*16
+    const int boff = (kh * TN + conv1_slot(wn * 32 + l31)) * 16;       // + (s*4 + 2j) * TN*16
 
     f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
 #pragma unroll
@@ -1879,7 +1892,7 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
         else split2_pair_f16(t[0], t[1], hq[u][cp], mq[u][cp]);
     };
     auto flush_unit = [&](int u, char* Xn) __attribute__((always_inline)) {
-        char* dst = Xn + (uoct[u] * TN + upx[u]) * 16;
+        char* dst = Xn + (uoct[u] * TN + conv1_slot(upx[u])) * 16;
         *reinterpret_cast<uint4*>(dst) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
         *reinterpret_cast<uint4*>(dst + 4 * TN * 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
         if (SPL == 3) *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[u][0], lq[u][1], lq[u][2], lq[u][3]);
@@ -2114,7 +2127,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
                     if (SPL == 3) split3_pair(t[0], t[1], hq[cp], mq[cp], lq[cp]);
                     else split2_pair_f16(t[0], t[1], hq[cp], mq[cp]);
                 }
-                char* dst = xres + st * XB + (uoct[u] * TN + upx[u]) * 16;
+                char* dst = xres + st * XB + (uoct[u] * TN + conv1_slot(upx[u])) * 16;
                 *reinterpret_cast<uint4*>(dst) = make_uint4(hq[0], hq[1], hq[2], hq[3]);
                 *reinterpret_cast<uint4*>(dst + 4 * TN * 16) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
                 if (SPL == 3) *reinterpret_cast<uint4*>(dst + 8 * TN * 16) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
@@ -2124,7 +2137,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
 
     // ---- walk over (cout tile, stage) pairs, streaming weight slabs ---------------------
     const int aoff = (kh * TM + l31) * 16;
-    const int boff = (kh * TN + wn * 32 + l31) * 16;
+    const int boff = (kh * TN + conv1_slot(wn * 32 + l31)) * 16;
     const int nit = nct * nstage;
     const char* wslab0 = reinterpret_cast<const char*>(a.wb) + (long)ct0 * nstage * CONVB1_SLAB_BYTES;   // slabs are (ct, stage)-major
     float wq[NWU][4];

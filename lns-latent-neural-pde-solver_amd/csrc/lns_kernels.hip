@@ -1335,6 +1335,20 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
     }
 }
 
+// f16x2 patch units are 32 bytes ([8 ch hi | 8 ch lo] fp16), one per patch pixel.  At a 32-byte lane stride the lanes l and
+// l + 8 of a ds_read_b128 group fall on the same banks (banking: (address / 4) mod 64) -- EVERY B-fragment read was a two-way
+// conflict (20 % of the kernel's LDS-array cycles in profiles/r03_pmc.json), and so was every patch write (lanes l, l + 4,
+// banking mod 32).  Which 16-byte half of a unit holds the hi term therefore alternates with bits 2 and 3 of the pixel's patch
+// index: consecutive pixels then cover all banks in both access shapes (any base offset).  Returns 0 or 16.
+// LNS_CONV3_NO_SWIZZLE: A/B build knob.
+__device__ __forceinline__ int convf_hi_half(int patch_index) {
+#ifdef LNS_CONV3_NO_SWIZZLE
+    return 0;
+#else
+    return (((patch_index >> 2) ^ (patch_index >> 3)) & 1) << 4;
+#endif
+}
+
 template <int NT, int NU, bool FUSE2, int MT = 2, int SPL = 3, int NTAP = 9, bool XOCT = false>
 __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // XOCT: the input tensor is channel-octet-interleaved ([Cin/8][Hin*Win][8] per sample, ConvArgs::x_oct; Cin % 8 == 0):
@@ -1444,6 +1458,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
             udm[u] = ok ? (unsigned)(sy[u] * a.Win + sx[u]) * (XOCT ? 32u : 4u) : 0u;
             uok[u] = ok ? 1.0f : 0.0f;                          // times the activation scale once the bound is known
             uslot[u] = (p < PLANE ? p : PLANE) * UB;
+            if (SPL == 2) uslot[u] += convf_hi_half(p < PLANE ? p : PLANE);     // byte offset of the unit's HI term (lo: ^ 16)
         }
     }
     // (the scale/shift table, the add vector and the activation bound are staged inside k_loop, BEHIND the first
@@ -1465,6 +1480,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // The 10th tap does not exist: in k-step 4 the kh=1 lanes multiply the shared zero unit with tap 8's
     // (finite) weights.
     int boff[NT], ltoff[NJ], aoff[NJ];
+    int bhi[NT][NJ];          // f16x2: byte offset of the hi term of (pixel tile nt, tap pair j) inside a patch buffer (lo: ^ 16)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
@@ -1476,6 +1492,11 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         const int tc = t < NTAP ? t : NTAP - 1;
         ltoff[j] = UP2 ? (((tc >> 1) + pa) * PW + (tc & 1) + pb) * UB : (((tc / 3) * a.dil) * PW + (tc % 3) * a.dil) * UB;
         aoff[j] = (tc * TM + l31) * 16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int off = boff[nt] + ltoff[j];
+            bhi[nt][j] = SPL == 2 ? off + convf_hi_half(off / UB) : off;
+        }
     }
     const bool ztap = kh != 0;                          // nine taps: in k-step 4 this lane half reads the zero unit
 
@@ -1542,6 +1563,11 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         else split2_pair_f16(v0, v1, hq[u][cp], mq[u][cp]);
     };
     auto flush_unit = [&](int u, char* Xn) __attribute__((always_inline)) {
+        if (SPL == 2) {      // swizzled halves (convf_hi_half): uslot is the hi term's slot, the lo term's is the other half
+            *reinterpret_cast<uint4*>(Xn + uslot[u]) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
+            *reinterpret_cast<uint4*>(Xn + (uslot[u] ^ 16)) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
+            return;
+        }
         char* dst = Xn + uslot[u];
         *reinterpret_cast<uint4*>(dst) = make_uint4(hq[u][0], hq[u][1], hq[u][2], hq[u][3]);
         *reinterpret_cast<uint4*>(dst + 16) = make_uint4(mq[u][0], mq[u][1], mq[u][2], mq[u][3]);
@@ -1570,9 +1596,15 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
                 af[s][mt] = *reinterpret_cast<const uint4*>(Ws + s * (NTAP * TM * 16) + mt * (32 * 16) + aoff[j]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const char* p = Xs + boff[nt] + ltoff[j];
-                if (j == NJ - 1 && (NTAP & 1)) p = ztap ? zunit : p;
-                bf[s][nt] = *reinterpret_cast<const uint4*>(p + s * 16);
+                if (SPL == 2) {
+                    const char* p = Xs + (bhi[nt][j] ^ (s * 16));
+                    if (j == NJ - 1 && (NTAP & 1)) p = ztap ? zunit : p;       // (both halves of the zero unit are zero)
+                    bf[s][nt] = *reinterpret_cast<const uint4*>(p);
+                } else {
+                    const char* p = Xs + boff[nt] + ltoff[j];
+                    if (j == NJ - 1 && (NTAP & 1)) p = ztap ? zunit : p;
+                    bf[s][nt] = *reinterpret_cast<const uint4*>(p + s * 16);
+                }
             }
         }
     };

@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     // The 10th tap does not exist: in k-step 4 the kh=1 lanes multiply the shared zero unit with tap 8's
     // (finite) weights.
     int boff[NT], ltoff[NJ], aoff[NJ];
-    int bhi[NT][NJ];          // f16x2: byte offset of the hi term of (pixel tile nt, tap pair j) inside a patch buffer (lo: ^ 16)
+    int bhi[NT][NJ], blo[NT][NJ];     // f16x2: byte offsets of the hi / lo terms of (pixel tile nt, tap pair j) inside a patch buffer
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + l31;
@@ -1496,6 +1496,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int off = boff[nt] + ltoff[j];
             bhi[nt][j] = SPL == 2 ? off + convf_hi_half(off / UB) : off;
+            blo[nt][j] = bhi[nt][j] ^ 16;
         }
     }
     const bool ztap = kh != 0;                          // nine taps: in k-step 4 this lane half reads the zero unit
@@ -1597,7 +1598,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (SPL == 2) {
-                    const char* p = Xs + (bhi[nt][j] ^ (s * 16));
+                    const char* p = Xs + (s ? blo[nt][j] : bhi[nt][j]);
                     if (j == NJ - 1 && (NTAP & 1)) p = ztap ? zunit : p;       // (both halves of the zero unit are zero)
                     bf[s][nt] = *reinterpret_cast<const uint4*>(p);
                 } else {

@@ -1483,8 +1483,12 @@ struct Runner {
                     if (B.bad) break;
 #ifdef LNS_TS
                     // diagnostic build: per-block phase timestamps of the layer named by $LNS_TS_LAYER, appended to $LNS_TS_FILE
-                    if (getenv("LNS_TS_FILE") && getenv("LNS_TS_LAYER") && op.name.find(getenv("LNS_TS_LAYER")) != std::string::npos &&
-                        (cv_is_split_3x3(op.variant) || op.variant == CV_B1)) {
+                    // ($LNS_TS_SKIP: leave the first N launches of the layer alone -- a stamp taken after seconds of sustained load)
+                    static long ts_seen = 0;
+                    const bool ts_match = getenv("LNS_TS_FILE") && getenv("LNS_TS_LAYER") && op.name.find(getenv("LNS_TS_LAYER")) != std::string::npos &&
+                                          (cv_is_split_3x3(op.variant) || op.variant == CV_B1);
+                    const long ts_skip = getenv("LNS_TS_SKIP") ? atol(getenv("LNS_TS_SKIP")) : 0, ts_max = getenv("LNS_TS_MAX") ? atol(getenv("LNS_TS_MAX")) : (1L << 40);
+                    if (ts_match && ts_seen++ >= ts_skip && ts_seen - 1 - ts_skip < ts_max) {
                         const long nblk = (long)a.tiles_x * a.tiles_y * a.cout_tiles * a.B;
                         long long* dts = nullptr;
                         if (hipMalloc(reinterpret_cast<void**>(&dts), nblk * 64) == hipSuccess) {

@@ -865,7 +865,12 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 // HW_ID, XCC_ID (tools/ts_analyze.py).  Expands to nothing in the shipped library.
 #ifdef LNS_TS
 #define LNS_TS_DECL long long ts_[6] = {0, 0, 0, 0, 0, 0};
-#if LNS_TS == 2
+#if LNS_TS == 3
+// -DLNS_TS=3: the clock the chip holds inside the K loop (MI355X_MICROARCH.md, DVFS give-back item 6): the 100 MHz wall clock
+// (s_memrealtime) and the shader clock counter (s_memtime) at loop start and loop end; slots 0 / 1 = wall clock, 2 / 3 = shader
+// clock.  In-kernel clock = (ts[3] - ts[2]) / (ts[1] - ts[0]) x 100 MHz (tools/clock_analyze.py).
+#define LNS_TSTAMP(i) if ((i) == 2 || (i) == 3) { __builtin_amdgcn_sched_barrier(0); ts_[(i) - 2] = wall_clock64(); ts_[i] = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#elif LNS_TS == 2
 #define LNS_TSTAMP(i) if ((i) == 5) { __builtin_amdgcn_sched_barrier(0); ts_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define LNS_TSTAMP(i) { __builtin_amdgcn_sched_barrier(0); ts_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }

@@ -146,6 +146,22 @@ def _pmc_busy(kernel_substr):
     return None
 
 
+def _held_clock():
+    """Clock the chip holds inside the nine-tap kernel's K loop during a sustained rollout (profiles/r*_inkernel_clock.json:
+    s_memtime / s_memrealtime stamps of a -DLNS_TS=3 build, tools/clock_probe.py).  bench.py cannot stamp the shipped kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_inkernel_clock.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            v = [l["clock_ghz_median"] for n, l in d["layers"].items() if ".conv" in n and "to_out" not in n and "in_proj" not in n]
+            if v:
+                return {"ghz": sum(v) / len(v), "nominal_ghz": 2.4, "layers": len(v), "source": os.path.basename(f)}
+        except Exception:
+            continue
+    return None
+
+
 def _total_traffic():
     """HBM bytes of one single-stream rollout of the headline workload from the newest committed counter passes."""
     import glob
@@ -206,6 +222,10 @@ def roofline_record(forms, classes, ms_per_step, path_tflops):
             # everything the launches issue (tap slot 10, channel / cout / pixel padding of ragged tiles): ~ MFMA busy x clock / 2.4 GHz
             "executed_frac": k["mfma_flops"] / sec / 1e12 / F16_MFMA_PEAK_TFLOPS,
             "mfma_busy_pmc": pmc,
+            # the peak above is at the nominal 2.4 GHz; in an MFMA-dense loop on real data the chip holds less (DVFS): the same
+            # achieved rate against the peak at the MEASURED in-kernel clock
+            "held_clock": _held_clock(),
+            "frac_at_held_clock": (ach / (peak * _held_clock()["ghz"] / 2.4)) if _held_clock() else None,
             "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
             "traffic": (td or {}).get("hbm_bytes_per_launch"), "traffic_detail": td,
             "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],

@@ -578,6 +578,8 @@ def main():
         tot_flops = sum(v["flops"] for v in classes.values())
         result["path_tflops_per_gpu"] = tot_flops * a.steps * n_gpus / dt / 1e12 / n_gpus
         result["roofline"] = roofline_record(forms, classes, result["ms_per_step"], result["path_tflops_per_gpu"])
+        # (event, launch, event) overhead measured around empty launches and already subtracted from every time above
+        result["roofline"]["event_overhead_us_subtracted_per_launch"] = eng.timing_event_overhead_us()
         tot = sum(v["ms"] for v in classes.values())
         result["kernel_classes"] = {n: {"ms": round(v["ms"], 3), "share": round(v["ms"] / tot, 4),
                                         "launches": v["launches"],

@@ -237,6 +237,8 @@ int lns_timing_info(const lns_engine* e, int index, char* name, int name_capacit
  * matrix pipe -- the three products of the split-operand scheme and every padded tap slot, channel and tile included --
  * in FLOP of the form's instruction ("f16x2 ...": fp16 MFMA, "fp32 MFMA ...": fp32 MFMA); `flops` above stays algorithmic. */
 int lns_timing_mfma_flops(const lns_engine* e, int index, double* mfma_flops);
+/* (index -1: instead of a record's FLOP, the per-launch overhead in MICROSECONDS that the engine measured for its
+ *  (event, launch, event) timing around empty launches and subtracted from every timed launch; -1000 before the first timed run) */
 
 /* Build-time features of this library: "experimental" = compiled with -DLNS_EXPERIMENTAL (the measured-slower kernel
  * forms behind op-level variants 15 / 16 / 18 / 19 exist; the shipped library does not carry them).  1 / 0; -1: unknown name.

@@ -1652,6 +1652,24 @@ struct Runner {
             e->timing.resize(CLS_COUNT);
             for (int i = 0; i < CLS_COUNT; ++i) e->timing[i].name = kClsName[i];
         }
+        if (e->timing_overhead_ms < 0.0) {
+            // calibration: (event, EMPTY launch, event) triples on the same stream; the empty kernel itself runs ~1 us
+            constexpr int NCAL = 64;
+            std::vector<float> v;
+            for (int i = 0; i < NCAL; ++i) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) break;
+                (void)hipEventRecord(a, stream);
+                (void)launch_empty(stream);
+                (void)hipEventRecord(b, stream);
+                (void)hipEventSynchronize(b);
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, a, b) == hipSuccess) v.push_back(ms);
+                (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+            }
+            std::sort(v.begin(), v.end());
+            e->timing_overhead_ms = v.empty() ? 0.0 : std::max(0.0, (double)v[v.size() / 2] - 1.0e-3);
+        }
         auto named = [&](const std::string& nm) {
             for (TimeRec& r : e->timing) if (r.name == nm) return &r;
             e->timing.emplace_back();
@@ -1667,6 +1685,7 @@ struct Runner {
                 if (ev.op->form[0]) t[1] = named(std::string(kClsName[ev.cls]) + "/" + ev.op->form);
                 t[0] = &e->timing[ev.cls];        // (after named(): emplace_back may move the vector)
             } else t[0] = named(std::string(kClsName[ev.cls]) + ":" + ev.op->name);
+            ms = std::max(ms - (float)e->timing_overhead_ms, 0.5e-3f);      // (never below half a microsecond per launch)
             for (TimeRec* r : t)
                 if (r) { r->ms += ms; r->launches += 1; r->flops += ev.op->flops; r->bytes += ev.op->bytes; r->mfma_flops += ev.op->mfma_flops; }
             (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
@@ -2232,6 +2251,7 @@ int lns_timing_info(const lns_engine* e, int i, char* name, int cap, double* ms,
 }
 
 int lns_timing_mfma_flops(const lns_engine* e, int i, double* mfma_flops) {
+    if (e && i == -1 && mfma_flops) { *mfma_flops = e->timing_overhead_ms * 1e3; return LNS_OK; }     // index -1: see include/lns.h
     if (!e || i < 0 || i >= (int)e->timing.size() || !mfma_flops) return LNS_EINVAL;
     *mfma_flops = e->timing[i].mfma_flops;
     return LNS_OK;

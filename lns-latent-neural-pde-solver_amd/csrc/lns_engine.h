@@ -182,4 +182,8 @@ struct lns_engine {
     std::vector<lns::TraceRec> trace;
     bool timing_on = false;
     std::vector<lns::TimeRec> timing;
+    // what an (event, launch, event) triple reports beyond the kernel's own duration: measured once per engine around empty
+    // launches (median of 64 pairs, minus ~1 us for the empty kernel itself) and subtracted from every timed launch, so that
+    // the per-form times agree with a rocprofv3 kernel trace (without it they read ~4.6 us per launch high)
+    double timing_overhead_ms = -1.0;
 };

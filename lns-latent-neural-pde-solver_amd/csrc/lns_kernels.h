@@ -304,6 +304,7 @@ hipError_t launch_amax(const float* x, long x_bs, long n, int B, unsigned* amax,
 hipError_t launch_amax_sticky(const unsigned* amax, int n, unsigned* flag, hipStream_t s);
 
 bool build_has_experimental();   // compiled with -DLNS_EXPERIMENTAL: the measured-slower kernel forms (variants 15, 16, 18, 19) exist
+hipError_t launch_empty(hipStream_t s);   // one empty block (calibration of the HIP-event timing overhead)
 hipError_t init_kernels();   // sets dynamic-LDS attributes; needs a GPU
 
 }  // namespace lns

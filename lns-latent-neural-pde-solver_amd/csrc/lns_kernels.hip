@@ -4985,6 +4985,13 @@ hipError_t launch_amax_sticky(const unsigned* amax, int n, unsigned* flag, hipSt
     return hipGetLastError();
 }
 
+// an empty launch: calibration of the per-launch overhead of the engine's HIP-event timing (Runner::finish)
+__global__ void empty_kernel() {}
+hipError_t launch_empty(hipStream_t s) {
+    hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 hipError_t init_kernels() {
     hipError_t e;
     const int maxlds = 160 * 1024;

@@ -395,6 +395,15 @@ class Engine:
     def timing_enable(self, on=True):
         self._check(self._L.lns_timing_enable(self._h, int(on)), "lns_timing_enable")
 
+    def timing_event_overhead_us(self):
+        """Per-launch overhead the engine measured for its HIP-event timing and subtracted from every timed launch."""
+        v = ctypes.c_double()
+        try:
+            self._check(self._L.lns_timing_mfma_flops(self._h, -1, ctypes.byref(v)), "lns_timing_mfma_flops")
+        except _lib.LnsLibraryError:
+            return None
+        return v.value if v.value >= 0 else None
+
     def timing(self):
         out = {}
         name = ctypes.create_string_buffer(_lib_key_cap())

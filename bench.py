@@ -208,7 +208,7 @@ def roofline_record(forms, classes, ms_per_step, path_tflops, headline=True):
         sec = k["ms"] * 1e-3
         ach = k["flops"] / sec / 1e12
         peak = F16_MFMA_PEAK_TFLOPS / SPLIT_EXEC_PER_ALGO
-        pmc = _pmc_busy("conv3_bf16x3_kernel<1, 1, false, 2, 2, 9>")
+        pmc = _pmc_busy("conv3_bf16x3_kernel<1, 1, false, 2, 2, 9")
         td = traffic_from_profiles("conv3x3")
         rec.update({
             "kernel": "conv3_bf16x3_kernel<NT, NU, false, MT, SPL=2, NTAP=9> (the nine-tap f16x2 3x3 implicit GEMM: fp32 operands as 2 fp16 "

@@ -10,17 +10,6 @@ R=$PWD; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 fail() { echo "FAILED: $1"; tail -5 "$2" 2>/dev/null; exit 1; }
 line() { tail -1 "$1" > "$2"; python3 -c "import json,sys; d=json.load(open('$2')); print('$3', round(d['value']), 'traj-steps/s', round(d['ms_per_step'],2), 'ms  frac', round(d['roofline']['frac'],3), 'check', d.get('check',{}).get('pass'), 'stable', d.get('check_stable',{}).get('pass'))"; }
 
-# 1. bench lines
-timeout -k 10 900 python bench.py > $O/bench_main.log 2>$O/bench_main.err || fail "bench main" $O/bench_main.err
-line $O/bench_main.log $O/${TAG}_bench_line.json headline
-timeout -k 10 400 python bench.py --rollout 256 --no-strict-fp32 --no-cpu-baseline --no-rccl-world1 > $O/b256.log 2>$O/b256.err || fail "bench T256" $O/b256.err
-line $O/b256.log $O/${TAG}_bench_line_ns2d_T256.json T256
-timeout -k 10 400 python bench.py --preset sw_96x192x5 --no-strict-fp32 --no-cpu-baseline --no-rccl-world1 > $O/bsw.log 2>$O/bsw.err || fail "bench sw" $O/bsw.err
-line $O/bsw.log $O/${TAG}_bench_line_sw_96x192x5.json sw
-timeout -k 10 400 python bench.py --preset twophase_cond --batch 32 --rollout 128 --no-strict-fp32 --no-cpu-baseline --no-rccl-world1 > $O/btp.log 2>$O/btp.err || fail "bench twophase" $O/btp.err
-line $O/btp.log $O/${TAG}_bench_line_twophase_cond.json twophase_cond
-echo "bench done"
-
 cd /tmp && export TMPDIR=/tmp
 QUIET="--no-cpu-baseline --no-strict-fp32 --no-check --no-check-stable --no-rccl-world1"
 # 2. kernel stats of the single-stream pass, every configuration (steps 4 + warmup 1 + the roofline pass = 6 rollouts)
@@ -45,8 +34,21 @@ done
 echo "pmc done"
 cd $R
 python3 tools/pmc_summary.py $O/${TAG}_pmc.json $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_WAIT_ANY $O/pmc_SQ_ACTIVE_INST_VALU $O/pmc_SQ_LDS_BANK_CONFLICT > $O/${TAG}_pmc_summary.txt 2>&1
-F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+F=$(ls -t $O/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1); W=$(ls -t $O/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
 python3 tools/make_traffic_json.py $F $W $O/${TAG}_traffic.json > $O/traffic.txt 2>&1
+# the bench lines quote the counter passes of THIS box and build: put them where bench.py looks (profiles/ of this copy)
+cp $O/${TAG}_pmc.json $O/${TAG}_traffic.json $R/profiles/
+# 3b. bench lines
+timeout -k 10 900 python bench.py > $O/bench_main.log 2>$O/bench_main.err || fail "bench main" $O/bench_main.err
+line $O/bench_main.log $O/${TAG}_bench_line.json headline
+timeout -k 10 400 python bench.py --rollout 256 --no-strict-fp32 --no-cpu-baseline --no-rccl-world1 > $O/b256.log 2>$O/b256.err || fail "bench T256" $O/b256.err
+line $O/b256.log $O/${TAG}_bench_line_ns2d_T256.json T256
+timeout -k 10 400 python bench.py --preset sw_96x192x5 --no-strict-fp32 --no-cpu-baseline --no-rccl-world1 > $O/bsw.log 2>$O/bsw.err || fail "bench sw" $O/bsw.err
+line $O/bsw.log $O/${TAG}_bench_line_sw_96x192x5.json sw
+timeout -k 10 400 python bench.py --preset twophase_cond --batch 32 --rollout 128 --no-strict-fp32 --no-cpu-baseline --no-rccl-world1 > $O/btp.log 2>$O/btp.err || fail "bench twophase" $O/btp.err
+line $O/btp.log $O/${TAG}_bench_line_twophase_cond.json twophase_cond
+echo "bench done"
+
 # 4. the roofline block recomputed from the rocprofv3 stats, every configuration
 for n in "" _ns2d_T256 _sw_96x192x5 _twophase_cond; do
   echo "== ${TAG}_serial_kernel_stats$n.csv vs the bench line of the same run" >> $O/${TAG}_roofline_from_stats.txt

@@ -9,8 +9,8 @@ import json
 import sys
 
 KERNELS = {   # class -> (substring of the kernel name, apply the guide's x2 FETCH_SIZE correction?)
-    "conv3x3": ("conv3_bf16x3_kernel<1, 1, false, 2, 2, 9>", False),
-    "conv3x3_up2_fused": ("conv3_bf16x3_kernel<1, 1, true, 2, 2, 4>", False),
+    "conv3x3": ("conv3_bf16x3_kernel<1, 1, false, 2, 2, 9", False),
+    "conv3x3_up2_fused": ("conv3_bf16x3_kernel<1, 1, true, 2, 2, 4", False),
     "conv1x1": ("conv1_bf16x3_kernel<true, false>", False),
     "conv1x1_stationary": ("conv1s_bf16x3_kernel", False),
     "fa_sandwich": ("fa_sandwich_f_kernel<2, 2, true, true", True),

@@ -215,12 +215,18 @@ __device__ __forceinline__ void stage_ss_from_partials(const ConvArgs& a, int b,
     __syncthreads();                                       // (wmax is written again by the caller)
 }
 
-__device__ __forceinline__ void stage_ss_bound(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid, int nthr) {
+// table = false (1x1 kernels without a prologue): `ssl` has no storage, only the bound is published
+__device__ __forceinline__ void stage_ss_bound(const ConvArgs& a, int b, float* ssl, unsigned* wmax, int tid, int nthr, bool table = true) {
     if (a.gn_part) {                                       // folded GroupNorm: its output bound is a layer constant
         stage_ss_from_partials(a, b, ssl, wmax, tid);
         return;
     }
     const bool has_ss = a.ss != nullptr;
+    if (!table) {                                          // identity prologue: bound = max |x| of the sample
+        if (!a.bound_final && (tid & 63) == 0)
+            wmax[tid >> 6] = abs_bits(a.amax_in ? __uint_as_float(amax_load(a.amax_in, b)) : a.amax_in_const);
+        return;
+    }
     if (a.bound_final) {                                   // the bound is a launch constant: only stage the table
         for (int c = tid; c < a.Cin_pad; c += nthr) {
             float2 st = make_float2(1.0f, 0.0f);
@@ -1814,6 +1820,9 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
 // banking is (address / 4) mod 32): a two-way conflict on every patch write -- 24 - 30 % of the LDS-array cycles of these
 // kernels in profiles/r03_pmc.json.  With the swap the eight lanes cover all 32 banks; the fragment reads (16 consecutive
 // pixels per ds_read_b128 lane group, banking mod 64) stay conflict-free.  LNS_CONV1_NO_SWIZZLE: A/B build knob.
+// (scale, shift) table of the prologue: only launches that have one pay for it (to_out's 512 channels: 4 KB -- the
+// difference between two and three blocks per CU for the fused form)
+__host__ __device__ inline int convb1_ss_floats(const ConvArgs& a) { return (a.ss != nullptr || a.gn_part != nullptr) ? a.Cin_pad * 2 : 0; }
 __device__ __forceinline__ int conv1_slot(int p) {
 #ifdef LNS_CONV1_NO_SWIZZLE
     return p;
@@ -1832,14 +1841,19 @@ __device__ __forceinline__ int conv1_slot(int p) {
 #define CONVB1_MIN_WAVES (LNS_CONV1_ONEACC ? 3 : 1)
 #define CONVB1_SLAB_BYTES (CONVB1_SPL * 4 * 64 * 16)   // splits x 4 octets x 64 couts x 8 ch
 template <bool VEC2, bool FUSE2>
-__global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN_WAVES) : CONVB1_MIN_WAVES) void conv1_bf16x3_kernel(ConvArgs a) {   // (the fused second conv needs the registers: two blocks per CU)
+// blocks per CU of the fused (1x1 + 1x1) form: a streaming kernel's HBM rate is its bytes in flight (one 16 KB stage per
+// block) over the memory latency -- two blocks per CU measured 4.1 - 4.2 TB/s on FABlock to_out (512 -> 64 at 64^2)
+#ifndef LNS_CONV1_FUSE2_WAVES
+#define LNS_CONV1_FUSE2_WAVES 3
+#endif
+__global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > LNS_CONV1_FUSE2_WAVES ? LNS_CONV1_FUSE2_WAVES : CONVB1_MIN_WAVES) : CONVB1_MIN_WAVES) void conv1_bf16x3_kernel(ConvArgs a) {
     constexpr int NTHR = 256, TM = 64, TN = 128, MT = 2, NT = 1, KC = 32, NJ = 2, NU = 2, SPL = CONVB1_SPL, NWU = CONVB1_SLAB_BYTES / 16 / 256;
     constexpr int XB = SPL * 4 * TN * 16;
     constexpr int BUF = XB + CONVB1_SLAB_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds = smem;                                                  // 2 x [Xb | Wb]
     float* ssl = reinterpret_cast<float*>(lds + 2 * BUF);              // [Cin_pad][2]
-    float* addv = ssl + a.Cin_pad * 2;                                 // [TM] bias + per-sample add of this cout tile
+    float* addv = ssl + convb1_ss_floats(a);                           // [TM] bias + per-sample add of this cout tile
     unsigned* wmax = reinterpret_cast<unsigned*>(addv + TM);           // [4] per-wave share of the activation bound
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -1965,7 +1979,7 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > 2 ? 2 : CONVB1_MIN
                 const int co = ct * TM + tid, cc = co < a.Cout ? co : 0;
                 addreg = (a.bias ? a.bias[cc] : 0.0f) + (a.badd ? a.badd[(long)b * a.Cout + cc] : 0.0f);
             }
-            stage_ss_bound(a, b, ssl, wmax, tid, NTHR);
+            stage_ss_bound(a, b, ssl, wmax, tid, NTHR, has_ss);
             if (tid < TM) addv[tid] = addreg;
         }
         __syncthreads();                                   // ssl / addv / wmax visible
@@ -2089,7 +2103,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
     char* xres = smem;                                                 // [stage 0..1][Xb]
     char* wbuf = smem + 2 * XB;                                        // [2][slab]
     float* ssl = reinterpret_cast<float*>(wbuf + 2 * CONVB1_SLAB_BYTES);
-    unsigned* wmax = reinterpret_cast<unsigned*>(ssl + a.Cin_pad * 2);   // [4] per-wave share of the activation bound
+    unsigned* wmax = reinterpret_cast<unsigned*>(ssl + convb1_ss_floats(a));   // [4] per-wave share of the activation bound
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -2137,7 +2151,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
                 }
             }
             if (st == 0) {
-                stage_ss_bound(a, b, ssl, wmax, tid, NTHR);  // behind the first stage's global loads
+                stage_ss_bound(a, b, ssl, wmax, tid, NTHR, has_ss);  // behind the first stage's global loads
                 __syncthreads();                            // ssl / wmax visible
                 LNS_TSTAMP(1)
                 if (SPL == 2) {
@@ -2279,7 +2293,7 @@ __global__ __launch_bounds__(256, CONVB1_MIN_WAVES) void conv1s_bf16x3_kernel(Co
     LNS_TS_DUMP
 }
 
-size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)a.Cin_pad * 8 + 64 * 4 + 16 + 16; }
+size_t convb1_lds_bytes(const ConvArgs& a) { return 2 * (CONVB1_SPL * 4 * 128 * 16 + CONVB1_SLAB_BYTES) + (size_t)convb1_ss_floats(a) * 4 + 64 * 4 + 16 + 16; }
 
 bool convb1_fits(const ConvArgs& a) {
     return a.ks == 1 && a.stride == 1 && (a.Cin_pad % 32) == 0 && a.wb != nullptr && convb1_lds_bytes(a) <= 150 * 1024;
@@ -2646,6 +2660,7 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
     for (int co = 0; co < 4; ++co)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[co][e] = 0.0f;
+    // (issuing the next 8 channels' loads before the current 8 are consumed measured no faster: 65.9 vs 65.7 us)
     for (int c0 = 0; c0 < C; c0 += 8) {
         float4 v[8];
 #pragma unroll

@@ -141,8 +141,13 @@ int lns_finalize_weights(lns_engine* e, int device);
  *   "fa_chunk_mb"     FABlock2D: in_proj -> sandwich -> to_out are issued per group of samples whose 512-plane tensor is at
  *                     most this many MB (it then stays in the 256 MB Infinity Cache between the three kernels instead of going
  *                     to HBM three times); 0 = whole batch per launch.  Cached plans are rebuilt.  Default: LNS_FA_CHUNK_MB
+ *   "fa_fused_gpb"    plane groups (of 16) one block of the fused FABlock kernel walks; 0 = automatic.  Cached plans are rebuilt.
  *   "track_nonfinite" 1: lns_check_finite also remembers the plan runs whose amax record has been reused since (the
  *                     earlier steps / decode groups of a rollout): one extra one-block launch per plan run (default 0)
+ * One option selects an ARITHMETIC FORM (results differ at rounding level, ~2e-7 relative on the decoded field):
+ *   "fa_fused"        1 (default; LNS_FA_FUSED): FABlock2D on 64 x 64 planes with 64 channels computes in_proj inside the
+ *                     sandwich kernel (csrc/fa_fused.inc) -- the heads * dim_head plane tensor is never stored; 0: in_proj as its
+ *                     own 1x1 convolution, then the sandwich.  Cached plans are rebuilt.
  * Defaults come from LNS_DECODE_GROUP / LNS_DECODE_STREAMS / LNS_NO_OVERLAP / LNS_PROP_PRIORITY at lns_create().
  * Changing an option changes the workspace size: call lns_prepare() again. */
 int lns_set_option(lns_engine* e, const char* name, long value);

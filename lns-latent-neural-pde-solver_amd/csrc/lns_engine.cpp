@@ -58,6 +58,7 @@ template <class T> static inline void fix(T*& p, const Bases& B) {
     const int sp = (int)(v >> 56);
     if (sp == SP_NULL) return;                                                       // already a device address
     if (sp >= 16 || !B.b[sp]) { B.bad = true; p = nullptr; return; }                 // tag without a base: never launch on it
+    if (sp == SP_CT && ((v >> 54) & 1)) { B.bad = true; p = nullptr; return; }       // float-segment constant Planner::finish() did not rebase
     p = reinterpret_cast<T*>(B.b[sp] + (v & 0x00FFFFFFFFFFFFFFull));
 }
 // A planner-tagged pointer (space id in bits 56+) that reached a launch without fix() would be a wild device address
@@ -812,13 +813,36 @@ struct Planner {
         emit_gn(xin, 1, 1e-5f, l.fa_g, l.fa_b, 0, l.name + ".in_norm");
         // in_proj records max |u| per sample: the sandwich's f16x2 form scales its planes by it (to_in's consumer, the
         // pooling, needs none)
-        TRef uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj", -1, true);
-        const size_t inproj_at = plan->ops.size() - 1;
+        // round 4: in_proj inside the sandwich kernel (fa_fused.inc) -- the plane tensor is only ever the sandwich's OUTPUT
+        static const bool fused_off = getenv("LNS_FA_SANDWICH_FP32") != nullptr || getenv("LNS_CONV_FP32_MFMA") != nullptr ||
+                                      getenv("LNS_CONV1_FP32_MFMA") != nullptr || getenv("LNS_FA_SANDWICH_BF16X3") != nullptr;
+        const bool fused_in = e->opt_fa_fused && !fused_off && fa_fused_fits(H, W, C, dh) && !e->packs[l.inproj].has_bias &&
+                              e->packs[l.inproj].cout == heads * dh && xin.ss != 0 && xin.gn_bound > 0.0f;
+        TRef uphi;
+        size_t inproj_at = 0, gs_off = 0;
+        uint64_t amax_g = 0;
+        if (fused_in) {
+            flush_gn(xin);                  // the pre-pass reads the finished (scale, shift) table
+            gs_off = arena.alloc(fa_fused_gs_bytes(B, H, W, C));
+            amax_g = new_amax(l.name + ".in_split");
+            Op op;
+            op.type = OP_FAGSPLIT; op.name = l.name + ".in_split"; op.cls = CLS_FASAND;
+            op.fg.x = as_ptr<const float>(xin.ptr); op.fg.x_bs = xin.bs; op.fg.Cin = C; op.fg.HW = H * W;
+            op.fg.ss = as_ptr<const float>(xin.ss); op.fg.bound = xin.gn_bound;
+            op.fg.gs = as_ptr<void>(tag(SP_WS, gs_off)); op.fg.amax_out = as_ptr<unsigned>(amax_g); op.fg.B = B;
+            op.bytes = 8.0 * B * C * H * W;
+            op.form = "FABlock input split (VALU)";
+            plan->ops.push_back(op);
+            uphi = alloc_t(heads * dh, H, W);
+        } else {
+            uphi = conv_same1(xin, l.inproj, ACT_NONE, nullptr, nullptr, l.name + ".in_proj", -1, true);
+            inproj_at = plan->ops.size() - 1;
+        }
         TRef v = conv_same1(xin, l.toin, ACT_NONE, nullptr, nullptr, l.name + ".to_in", -1, false);
         // (chunked: in_proj is re-issued AFTER the pooling / reducer / low-rank ops, so the GroupNorm table it reads must
         //  outlive their allocations)
         const bool fused_out = getenv("LNS_FA_NO_FUSE_TO_OUT") == nullptr && can_fuse_1x1(e->packs[l.out1], e->packs[l.out3]);
-        const bool will_chunk = fused_out && fa_chunk_samples((size_t)heads * dh * H * W * 4) > 0;
+        const bool will_chunk = !fused_in && fused_out && fa_chunk_samples((size_t)heads * dh * H * W * 4) > 0;
         if (!will_chunk) free_t(xin);
         // axis pooling
         const size_t mx_off = arena.alloc((size_t)B * H * C * 4), my_off = arena.alloc((size_t)B * W * C * 4);
@@ -898,7 +922,54 @@ struct Planner {
             }
         }
         free_t(qkx); free_t(qky);
-        {
+        if (fused_in) {
+            const ConvPack& pk = e->packs[l.inproj];
+            const int planes = heads * dh;
+            std::vector<float> wm((size_t)planes * C);
+            {   // [planes][C] from the (possibly concatenated) state_dict tensors
+                size_t row = 0;
+                for (const std::string& key : pk.wkeys) {
+                    const Param& p = e->params[e->pindex.at(key)];
+                    if (p.numel() % (size_t)C) throw std::runtime_error("in_proj weight shape: " + key);
+                    std::copy(p.host.begin(), p.host.end(), wm.begin() + row * C);
+                    row += p.numel() / C;
+                }
+                if ((int)row != planes) throw std::runtime_error("in_proj weight rows: " + l.name);
+            }
+            float wmax = 0.0f, rowmax = 0.0f;
+            for (int r = 0; r < planes; ++r) {
+                float rs = 0.0f;
+                for (int k = 0; k < C; ++k) { const float v = fabsf(wm[(size_t)r * C + k]); wmax = std::max(wmax, v); rs += v; }
+                rowmax = std::max(rowmax, rs);
+            }
+            if (!(wmax > 0.0f) || !std::isfinite(rowmax)) { wmax = 1.0f; rowmax = std::max(rowmax, 1.0f); }
+            const float wscale = exp2f(floorf(log2f(16000.0f / wmax)));
+            std::vector<float> img(fa_fused_weight_bytes(planes, C) / 4);
+            fa_fused_pack_weight(img.data(), wm.data(), planes, C, wscale);
+            Op op;
+            op.type = OP_FAFUSED; op.name = l.name + ".sandwich"; op.cls = CLS_FASAND;
+            op.ff.gs = as_ptr<const void>(tag(SP_WS, gs_off)); op.ff.amax_g = as_ptr<const unsigned>(amax_g); op.ff.bound = xin.gn_bound;
+            op.ff.wp = as_ptr<const void>(const_floats(img)); op.ff.w_inv = 1.0f / wscale;
+            op.ff.wrow_max = rowmax * (1.0f + 1e-6f);       // (the device multiplies it by max |G| in fp32: keep the product a bound)
+            op.ff.kx = as_ptr<const float>(tag(SP_WS, kx_off)); op.ff.ky = as_ptr<const float>(tag(SP_WS, ky_off));
+            op.ff.B = B; op.ff.heads = heads; op.ff.C = dh; op.ff.Cin = C; op.ff.H = H; op.ff.W = W; op.ff.eps = 1e-5f; op.ff.instnorm = 1;
+            op.ff.out = as_ptr<float>(uphi.ptr);
+            static const bool no_rev = getenv("LNS_FA_NO_REVERSE") != nullptr;
+            op.ff.b_rev = no_rev ? 0 : 1;
+            {   // plane groups per block (scheduling only; "fa_fused_gpb" / LNS_FA_FUSED_GPB): by default all four groups of a
+                // head while the grid keeps two blocks per CU's worth of work
+                const int groups = dh / 16;
+                int gpb = e->opt_fa_fused_gpb > 0 ? std::min(e->opt_fa_fused_gpb, groups) : 4;
+                while (gpb > 1 && (groups % gpb || (e->opt_fa_fused_gpb <= 0 && (long)B * heads * (groups / gpb) < 512))) --gpb;
+                op.ff.gpb = gpb;
+            }
+            op.flops = 2.0 * B * heads * dh * ((double)H * W * W + (double)H * H * W) + 2.0 * B * planes * (double)C * H * W;
+            op.bytes = 4.0 * B * ((double)planes + C) * H * W;
+            op.mfma_flops = (2.0 * B * heads * dh * ((double)H * W * W + (double)H * H * W) + 2.0 * B * planes * (double)C * H * W) * 3.0;
+            op.form = "f16x2 FABlock in_proj + sandwich";
+            plan->ops.push_back(op);
+            arena.release(gs_off);
+        } else {
             Op op;
             op.type = OP_FASAND; op.name = l.name + ".sandwich"; op.cls = CLS_FASAND;
             op.fs.u = as_ptr<const float>(uphi.ptr); op.fs.kx = as_ptr<const float>(tag(SP_WS, kx_off));
@@ -1240,6 +1311,7 @@ struct Planner {
             if (op.type == OP_FALRK || op.type == OP_FALRK2) rebase(op.fl.cs);
             if (op.type == OP_FALRK2) rebase(op.fl2.cs);
             if (op.type == OP_CONDBASE) rebase(op.cb.freqs);
+            if (op.type == OP_FAFUSED) rebase(op.ff.wp);
         }
         plan->arena_bytes = arena.high;
         plan->amax_bytes = (size_t)amax_used * B * LNS_AMAX_SUB * 4;
@@ -1566,6 +1638,45 @@ struct Runner {
                     rc = launch_fa_sandwich(a, stream);
                     break;
                 }
+                case OP_FAGSPLIT: {
+                    FaGsplitArgs a = op.fg;
+                    fix(a.x, B); fix(a.ss, B); fix(a.gs, B); fix(a.amax_out, B); fixbs(a.x_bs, B);
+                    rc = launch_fa_gsplit(a, stream);
+                    break;
+                }
+                case OP_FAFUSED: {
+                    FaFusedArgs a = op.ff;
+                    fix(a.gs, B); fix(a.amax_g, B); fix(a.wp, B); fix(a.kx, B); fix(a.ky, B); fix(a.out, B);
+                    a.dbg_ts = nullptr;
+#ifdef FAF_TS
+                    // diagnostic build: wave 0's phase timestamps of every block, appended to $LNS_TS_FILE
+                    if (getenv("LNS_TS_FILE")) {
+                        const long nblk = (long)a.B * a.heads * (a.C / 16 / a.gpb);
+                        long long* dts = nullptr;
+                        if (hipMalloc(reinterpret_cast<void**>(&dts), nblk * 24 * 8) == hipSuccess) {
+                            (void)hipMemsetAsync(dts, 0, nblk * 24 * 8, stream);
+                            a.dbg_ts = dts;
+                            rc = launch_fa_fused(a, stream);
+                            (void)hipStreamSynchronize(stream);
+                            std::vector<long long> hts(nblk * 24);
+                            (void)hipMemcpy(hts.data(), dts, nblk * 24 * 8, hipMemcpyDeviceToHost);
+                            (void)hipFree(dts);
+                            if (FILE* f = fopen(getenv("LNS_TS_FILE"), "a")) {
+                                fprintf(f, "# launch %s blocks=%ld\n", op.name.c_str(), nblk);
+                                for (long i = 0; i < nblk; ++i) {
+                                    fprintf(f, "%ld", i);
+                                    for (int k = 0; k < 24; ++k) fprintf(f, " %lld", hts[i * 24 + k]);
+                                    fprintf(f, "\n");
+                                }
+                                fclose(f);
+                            }
+                            break;
+                        }
+                    }
+#endif
+                    rc = launch_fa_fused(a, stream);
+                    break;
+                }
                 case OP_CONDBASE: {
                     CondBaseArgs a = op.cb;
                     fix(a.param, B); fix(a.freqs, B); fix(a.w0_t, B); fix(a.b0, B); fix(a.w2_t, B); fix(a.b2, B); fix(a.ce, B);
@@ -1810,6 +1921,8 @@ int lns_create(const lns_config* cfg, lns_engine** out) {
     if (getenv("LNS_NO_OVERLAP")) e->opt_overlap = 0;
     if (getenv("LNS_PROP_PRIORITY")) e->opt_prop_priority = 1;
     if (const char* v = getenv("LNS_FA_CHUNK_MB")) e->opt_fa_chunk_mb = atoi(v);
+    if (const char* v = getenv("LNS_FA_FUSED")) e->opt_fa_fused = atoi(v) != 0;
+    if (const char* v = getenv("LNS_FA_FUSED_GPB")) e->opt_fa_fused_gpb = std::max(0, atoi(v));
     e->cfg.ae_prefix[sizeof(e->cfg.ae_prefix) - 1] = 0;
     e->cfg.prop_prefix[sizeof(e->cfg.prop_prefix) - 1] = 0;
     try {
@@ -1879,6 +1992,19 @@ int lns_set_option(lns_engine* e, const char* name, long value) {
     else if (n == "decode_streams") { if (value < 1 || value > NDEC) return LNS_EINVAL; e->opt_decode_streams = (int)value; }
     else if (n == "overlap") e->opt_overlap = value != 0;
     else if (n == "track_nonfinite") e->opt_track_nonfinite = value != 0;
+    else if (n == "fa_fused" || n == "fa_fused_gpb") {
+        if (n == "fa_fused_gpb" && (value < 0 || value > 64)) return LNS_EINVAL;
+        const bool changed = n == "fa_fused" ? e->opt_fa_fused != (value != 0) : e->opt_fa_fused_gpb != (int)value;
+        if (changed) {                                  // a planning rule of the decoder / encoder: cached plans are rebuilt
+            DeviceGuard dg(e);
+            for (auto* m : {&e->enc_plans, &e->dec_plans}) {
+                for (auto& kv : *m) if (kv.second.d_consts) (void)hipFree(kv.second.d_consts);
+                m->clear();
+            }
+        }
+        if (n == "fa_fused") e->opt_fa_fused = value != 0;
+        else e->opt_fa_fused_gpb = (int)value;
+    }
     else if (n == "fa_chunk_mb") {
         if (value < 0 || value > 4096) return LNS_EINVAL;
         if (e->opt_fa_chunk_mb != (int)value) {         // a planning rule of the decoder / encoder: cached plans are rebuilt

@@ -74,7 +74,7 @@ struct Layer {
 enum Space { SP_NULL = 0, SP_WS = 1, SP_WT = 2, SP_CT = 3, SP_EXT0 = 4 };   // ext slots: 4..11
 enum ExtSlot { EX_IN = 0, EX_OUT = 1, EX_PARAM = 2, EX_SS = 3 /* [B][C][2] affine prologue of the input (lns_encode_affine) */, EX_COUNT = 4 };
 
-enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FARED2, OP_FALRK, OP_FALRK2, OP_FASAND, OP_CONDBASE, OP_CONDBLK,
+enum OpType { OP_CONV, OP_GNSTATS, OP_LNPE, OP_ATTN, OP_FAPOOL, OP_FARED, OP_FARED2, OP_FALRK, OP_FALRK2, OP_FASAND, OP_FAGSPLIT, OP_FAFUSED, OP_CONDBASE, OP_CONDBLK,
               OP_APPLY, OP_SPECTRAL, OP_FCOMBINE, OP_VECLIN, OP_TRACE };
 
 struct Op {
@@ -103,6 +103,8 @@ struct Op {
     FaReducerArgs fr = {}, fr2 = {};     // fr2 / fl2: second axis of the merged two-axis launches
     FaLrkArgs fl = {}, fl2 = {};
     FaSandwichArgs fs = {};
+    FaGsplitArgs fg = {};      // FABlock with in_proj inside the sandwich (fa_fused.inc): the input split pre-pass
+    FaFusedArgs ff = {};       // ... and the fused kernel
     CondBaseArgs cb = {};
     CondBlockArgs ck = {};
     ApplyArgs ap = {};
@@ -165,6 +167,10 @@ struct lns_engine {
     // that it is still in the Infinity Cache (256 MB, shared by the streams of the overlapped rollout) when the next kernel
     // reads it; 0 = whole batch per launch.  Scheduling only: the bits do not change.
     int opt_fa_chunk_mb = 0;
+    // FABlock2D at 64 x 64 planes, 64 channels: in_proj computed inside the sandwich kernel (fa_fused.inc) instead of written to
+    // and read from HBM as a heads * dim_head plane tensor.  A planning rule ("fa_fused" option / LNS_FA_FUSED).
+    int opt_fa_fused = 1;
+    int opt_fa_fused_gpb = 0;      // plane groups (of 16) per block of the fused kernel; 0 = automatic (scheduling only)
     // what the last top-level call ran, for lns_check_finite: (plan kind, plan key, arena offset inside the caller's
     // workspace) -- no pointers into the plan caches or the workspace, which the caller may drop at any time -- plus
     // the workspace and batch of that call.  Cleared whenever plans are dropped.

@@ -240,6 +240,28 @@ struct FaSandwichArgs {
 hipError_t launch_fa_sandwich(const FaSandwichArgs& a, hipStream_t s);
 size_t fa_sandwich_lds_bytes(int H, int W);
 
+// FABlock2D with in_proj inside the sandwich (fa_fused.inc): the heads * dim_head plane tensor between in_proj and the
+// sandwich is never stored.  64 x 64 planes, 64 input channels, dim_head a multiple of 16.
+//   launch_fa_gsplit : G = x * scale + shift (the in_norm GroupNorm) once per sample as two fp16 terms of G * S (S: the power
+//                      of two that puts `bound` at 2^14 .. 2^15), [B][H*W/16][Cin/32][hi | lo][4 quarters][16 pixels][8]; records max |G| per sample
+//   launch_fa_fused  : per (sample, head, 16 planes): P = W G band by band on v_mfma_f32_16x16x32_f16, Y = Kx P Ky^T,
+//                      InstanceNorm, store
+struct FaGsplitArgs { const float* x; long x_bs; int Cin, HW; const float* ss; float bound; void* gs; unsigned* amax_out; int B; };
+struct FaFusedArgs {
+    const void* gs; const unsigned* amax_g; float bound;      // the pre-pass's output, its max |G| record, the bound it scaled by
+    const void* wp; float w_inv, wrow_max;                    // fa_fused_pack_weight image, 1 / its scale, max_c sum_k |W[c][k]|
+    const float* kx; const float* ky;
+    int B, heads, C, Cin, H, W; float eps; int instnorm; float* out; int b_rev;
+    int gpb;               // plane groups (of 16) one block walks: Kx / Ky of the (sample, head) are staged once for them
+    long long* dbg_ts;     // -DFAF_TS builds: [blocks][24] phase timestamps of wave 0 (null otherwise)
+};
+bool fa_fused_fits(int H, int W, int Cin, int dim_head);
+size_t fa_fused_gs_bytes(int B, int H, int W, int Cin);
+size_t fa_fused_weight_bytes(int planes, int Cin);
+void fa_fused_pack_weight(void* dst, const float* w, int planes, int Cin, float wscale);
+hipError_t launch_fa_gsplit(const FaGsplitArgs& a, hipStream_t s);
+hipError_t launch_fa_fused(const FaFusedArgs& a, hipStream_t s);
+
 // conditional propagator: per-sample embedding MLPs (tiny; step-invariant) ------
 struct CondBaseArgs {            // ce = W2 act(W0 fourier_embedding(param) + b0) + b2
     const float* param; int B, E;

@@ -4544,6 +4544,8 @@ static size_t fa_sandwich_f_lds_bytes(int HT, int WT) {
     return (2 * HB * (HB + 8) + 2 * WB * (WB + 8) + (size_t)4 * 2 * 32 * (WB + 8)) * 2 + 64;
 }
 
+#include "fa_fused.inc"
+
 constexpr size_t fa_sandwich_b_lds_const(int HT, int WT, int nwv) {
     return ((size_t)3 * HT * 32 * (HT * 32 + 8) + (size_t)3 * WT * 32 * (WT * 32 + 8) + (size_t)nwv * 3 * 32 * (WT * 32 + 8)) * 2;
 }
@@ -5076,6 +5078,7 @@ hipError_t init_kernels() {
     }
     LNS_SET_SWF(1, 1) LNS_SET_SWF(1, 2) LNS_SET_SWF(2, 1) LNS_SET_SWF(2, 2) LNS_SET_SWF(2, 3)
 #undef LNS_SET_SWF
+    LNS_SET_LDS((fa_fused_kernel<2>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))

@@ -667,6 +667,44 @@ def test_overlapped_rollout_equals_single_stream():
             assert torch.equal(y, ref), opts
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [3, 16])
+def test_fablock_in_proj_inside_the_sandwich(B):
+    """FABlock2D at 64 x 64 planes: in_proj computed inside the sandwich kernel (csrc/fa_fused.inc, the default) against the
+    three-kernel form (in_proj convolution -> sandwich -> to_out) on the same latents: rounding-level agreement of the decoded
+    fields, both within the oracle's tolerance; the plane groups a block walks (1, 2, 4) and the batch-dependent block order
+    (B % 8 == 0 or not) never change a bit."""
+    _need_gpu()
+    import gpu_checks as gc
+    from lns_amd import config, filler
+    args = config.preset("ns2d_128")
+    model, orc = gc.build_models(args, 1)
+    x = filler.normal("xfa", (B, args.in_channels, args.Ly, args.Lx), 7)
+    xd = torch.from_numpy(x).cuda()
+    eng = model._engine(xd)
+    z = eng.encode(xd)
+    try:
+        eng.set_option("fa_fused", 0)
+        y3 = eng.decode(z).clone()
+        eng.set_option("fa_fused", 1)
+        yf = eng.decode(z).clone()
+        assert torch.isfinite(yf).all()
+        assert rel_l2(yf.cpu().numpy(), y3.cpu().numpy()) < 1e-6
+        assert not torch.equal(yf, y3)          # (the fused form really ran: another summation order)
+        for gpb in (1, 2, 4, 0):
+            eng.set_option("fa_fused_gpb", gpb)
+            assert torch.equal(eng.decode(z), yf), gpb
+        # a sample's result does not depend on the batch around it
+        sub = eng.decode(z[1:2].contiguous())
+        assert torch.equal(sub, yf[1:2])
+        ref = orc.z_to_x(z[:2].cpu().numpy())
+        assert rel_l2(yf[:2].cpu().numpy(), ref) < STAGE_TOL * 2
+        assert rel_l2(y3[:2].cpu().numpy(), ref) < STAGE_TOL * 2
+    finally:
+        eng.set_option("fa_fused", 1)
+        eng.set_option("fa_fused_gpb", 0)
+
+
 def test_full_size_rollout_properties():
     """BASELINE config 2 shape (B=64, T=64 is the bench; here T=4 to bound memory/time):
     finite, per-sample independent (bitwise) and close to the oracle on a sub-batch."""

@@ -31,6 +31,8 @@ PATTERNS = [   # form -> regex on the demangled kernel name
     ("fp32 MFMA 3x3", r"conv_mfma_kernel<\d+, \d+, \d+, \d+, 3,"),
     ("fp32 MFMA 1x1", r"conv_mfma_kernel<\d+, \d+, \d+, \d+, 1,"),
     ("f16x2 FABlock sandwich", r"fa_sandwich_f_kernel"),
+    ("f16x2 FABlock in_proj + sandwich", r"fa_fused_kernel"),
+    ("FABlock input split (VALU)", r"fa_gsplit_kernel"),
     ("f16x2 attention", r"attention_f_kernel"),
 ]
 

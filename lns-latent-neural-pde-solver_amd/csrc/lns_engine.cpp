@@ -956,6 +956,7 @@ struct Planner {
             op.ff.out = as_ptr<float>(uphi.ptr);
             static const bool no_rev = getenv("LNS_FA_NO_REVERSE") != nullptr;
             op.ff.b_rev = no_rev ? 0 : 1;
+            op.ff.single_buffer = e->opt_fa_fused == 1 ? 1 : 0;
             {   // plane groups per block (scheduling only; "fa_fused_gpb" / LNS_FA_FUSED_GPB): by default all four groups of a
                 // head while the grid keeps two blocks per CU's worth of work
                 const int groups = dh / 16;
@@ -1921,7 +1922,7 @@ int lns_create(const lns_config* cfg, lns_engine** out) {
     if (getenv("LNS_NO_OVERLAP")) e->opt_overlap = 0;
     if (getenv("LNS_PROP_PRIORITY")) e->opt_prop_priority = 1;
     if (const char* v = getenv("LNS_FA_CHUNK_MB")) e->opt_fa_chunk_mb = atoi(v);
-    if (const char* v = getenv("LNS_FA_FUSED")) e->opt_fa_fused = atoi(v) != 0;
+    if (const char* v = getenv("LNS_FA_FUSED")) e->opt_fa_fused = std::min(2, std::max(0, atoi(v)));
     if (const char* v = getenv("LNS_FA_FUSED_GPB")) e->opt_fa_fused_gpb = std::max(0, atoi(v));
     e->cfg.ae_prefix[sizeof(e->cfg.ae_prefix) - 1] = 0;
     e->cfg.prop_prefix[sizeof(e->cfg.prop_prefix) - 1] = 0;
@@ -1994,7 +1995,8 @@ int lns_set_option(lns_engine* e, const char* name, long value) {
     else if (n == "track_nonfinite") e->opt_track_nonfinite = value != 0;
     else if (n == "fa_fused" || n == "fa_fused_gpb") {
         if (n == "fa_fused_gpb" && (value < 0 || value > 64)) return LNS_EINVAL;
-        const bool changed = n == "fa_fused" ? e->opt_fa_fused != (value != 0) : e->opt_fa_fused_gpb != (int)value;
+        if (n == "fa_fused" && (value < 0 || value > 2)) return LNS_EINVAL;
+        const bool changed = n == "fa_fused" ? e->opt_fa_fused != (int)value : e->opt_fa_fused_gpb != (int)value;
         if (changed) {                                  // a planning rule of the decoder / encoder: cached plans are rebuilt
             DeviceGuard dg(e);
             for (auto* m : {&e->enc_plans, &e->dec_plans}) {
@@ -2002,7 +2004,7 @@ int lns_set_option(lns_engine* e, const char* name, long value) {
                 m->clear();
             }
         }
-        if (n == "fa_fused") e->opt_fa_fused = value != 0;
+        if (n == "fa_fused") e->opt_fa_fused = (int)value;
         else e->opt_fa_fused_gpb = (int)value;
     }
     else if (n == "fa_chunk_mb") {

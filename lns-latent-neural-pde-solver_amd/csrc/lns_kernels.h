@@ -252,6 +252,8 @@ struct FaFusedArgs {
     const void* wp; float w_inv, wrow_max;                    // fa_fused_pack_weight image, 1 / its scale, max_c sum_k |W[c][k]|
     const float* kx; const float* ky;
     int B, heads, C, Cin, H, W; float eps; int instnorm; float* out; int b_rev;
+    int single_buffer;     // 1: fa_fused_kernel (one band image, in_proj and sandwich phases alternate); 0: fa_fused2_kernel (two
+                           // swizzled band images: the next band's in_proj runs inside the sandwich, one barrier per band).  Same bits.
     int gpb;               // plane groups (of 16) one block walks: Kx / Ky of the (sample, head) are staged once for them
     long long* dbg_ts;     // -DFAF_TS builds: [blocks][24] phase timestamps of wave 0 (null otherwise)
 };

@@ -5079,6 +5079,7 @@ hipError_t init_kernels() {
     LNS_SET_SWF(1, 1) LNS_SET_SWF(1, 2) LNS_SET_SWF(2, 1) LNS_SET_SWF(2, 2) LNS_SET_SWF(2, 3)
 #undef LNS_SET_SWF
     LNS_SET_LDS((fa_fused_kernel<2>))
+    LNS_SET_LDS((fa_fused2_kernel<2>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))

@@ -167,7 +167,7 @@ class Engine:
 
     def set_option(self, name, value):
         """Scheduling options of the rollout (include/lns.h lns_set_option): decode_group, decode_streams, overlap,
-        prop_priority, track_nonfinite, fa_chunk_mb, fa_fused_gpb.  Results never depend on them.  "fa_fused" (default 1) selects
+        prop_priority, track_nonfinite, fa_chunk_mb, fa_fused_gpb.  Results never depend on them.  "fa_fused" (default 2; 1 = single-buffered kernel, same bits; 0 = off) selects
         the arithmetic form of FABlock2D at 64 x 64 planes (in_proj inside the sandwich kernel): ~2e-7 relative on the fields."""
         self._check(self._L.lns_set_option(self._h, name.encode(), int(value)), "lns_set_option")
         self._ws.clear()                      # the workspace size depends on the options

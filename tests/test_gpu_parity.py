@@ -686,9 +686,12 @@ def test_fablock_in_proj_inside_the_sandwich(B):
     try:
         eng.set_option("fa_fused", 0)
         y3 = eng.decode(z).clone()
-        eng.set_option("fa_fused", 1)
+        eng.set_option("fa_fused", 2)
         yf = eng.decode(z).clone()
         assert torch.isfinite(yf).all()
+        eng.set_option("fa_fused", 1)           # the single-buffered form of the kernel: the same arithmetic
+        assert torch.equal(eng.decode(z), yf)
+        eng.set_option("fa_fused", 2)
         assert rel_l2(yf.cpu().numpy(), y3.cpu().numpy()) < 1e-6
         assert not torch.equal(yf, y3)          # (the fused form really ran: another summation order)
         for gpb in (1, 2, 4, 0):
@@ -701,7 +704,7 @@ def test_fablock_in_proj_inside_the_sandwich(B):
         assert rel_l2(yf[:2].cpu().numpy(), ref) < STAGE_TOL * 2
         assert rel_l2(y3[:2].cpu().numpy(), ref) < STAGE_TOL * 2
     finally:
-        eng.set_option("fa_fused", 1)
+        eng.set_option("fa_fused", 2)
         eng.set_option("fa_fused_gpb", 0)
 
 

@@ -170,6 +170,22 @@ def test_hot_loops_keep_their_instruction_budget():
     assert segs1 and min(c["valu"] - v.get("v_mov_b32_e32", 0) for _, c, v in segs1) <= 70
 
 
+def test_fused_fablock_kernel_keeps_its_registers():
+    """The double-buffered fused FABlock kernel (csrc/fa_fused.inc) lives at the edge of the register file: 128 of a wave's
+    256 registers are accumulators.  A change that makes it spill costs more than the fusion gains (the
+    variants with 17 - 56 spilled registers measured 5 - 15 % slower), and the code object's notes show it without a GPU."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from lns_amd import _lib
+    res = kernel_resources.resources(_lib.LIB_PATH)
+    k = [v for n, v in res.items() if "fa_fused2_kernel" in n]
+    assert len(k) == 1
+    assert k[0]["vgpr_spill"] == 0 and k[0]["scratch"] == 0 and k[0]["vgpr"] + k[0]["agpr"] <= 256, k[0]
+    k1 = [v for n, v in res.items() if "fa_fused_kernel" in n]
+    assert len(k1) == 1 and k1[0]["vgpr_spill"] <= 16, k1
+
+
 def test_set_option_validates_names_and_ranges():
     from lns_amd import config, engine, _lib
     e = engine.Engine(engine.make_config(config.preset("ns2d_mini"), ae_prefix="vq_ae.", prop_prefix="propagator."))

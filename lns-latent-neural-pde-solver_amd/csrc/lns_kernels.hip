@@ -24,6 +24,14 @@
 
 namespace lns {
 
+// cache policy of the big output streams (A/B build knobs; 0 plain, 2 nt, 16 sc1): the split-operand conv epilogue's stores and
+// the sandwich kernels' plane stores
+#ifndef LNS_CONV_STORE_AUX
+#define LNS_CONV_STORE_AUX 0
+#endif
+#ifndef LNS_SAND_STORE_AUX
+#define LNS_SAND_STORE_AUX 0
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Exact (erf) GELU without the ~60-instruction library erff: 1 + erf(x) = 2 - erfc(x) for x >= 0 and erfc(|x|) for
@@ -1198,7 +1206,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 for (int r = 0; r < 16; ++r) {
                     const int so = ((ct * TM + mt * 32 + (r & 3) + 8 * (r >> 2)) * HWo) * 4;     // uniform
                     const float v = acc[mt][nt][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, vo, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, vo, so, LNS_CONV_STORE_AUX);
                     am = max(am, abs_bits(v));
                 }
         }
@@ -1233,7 +1241,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 for (int r = 0; r < 16; ++r) {
                     const unsigned vr = vo + (unsigned)(((ct * TM + mt * 32 + (r & 3) + 8 * (r >> 2)) * HWo) * 4);
                     const float v = acc[mt][nt][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)vr, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)vr, 0, LNS_CONV_STORE_AUX);
                     am = max(am, vr < nb ? abs_bits(v) : 0u);
                     if (stats && !SHALF) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
                 }
@@ -4530,11 +4538,11 @@ __global__ __launch_bounds__(256, (WT <= 2 && (VEC || HT * WT < 4) ? 2 : 1)) voi
                     const int so = ((it * 32 + (r & 3) + 8 * (r >> 2)) * W + lt * 32) * 4;      // uniform
                     const float v = (Yh[it][lt][r] - mean) * rstd;
                     if (FULL) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, vo, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, vo, so, LNS_SAND_STORE_AUX);
                     } else {        // ragged plane: the range check masks (the row offset in the VGPR, invalid lanes at 2^31)
                         const int i = it * 32 + drow(r, kh), l = lt * 32 + l31;
                         const unsigned vr = (i < H && l < W) ? (unsigned)(vo + so) : 0x80000000u;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, (int)vr, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, (int)vr, 0, LNS_SAND_STORE_AUX);
                     }
                 }
     }

@@ -1924,7 +1924,12 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > LNS_CONV1_FUSE2_WA
                 // (flat 8-byte loads: the buffer form of this streaming read measured 7 % slower on the HBM-bound
                 //  64 -> 64 layer at 128^2, 122 vs 114 us, although it needs one vector instruction less per load)
                 const char* cb = reinterpret_cast<const char*>(xb) + (long)min(c, cin_m1) * hw4;     // scalar
+#ifdef LNS_CONV1_NT_LOADS
+                const f32x2 tv = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(cb + (unsigned)udm[0]));
+                const float2 t = make_float2(tv[0], tv[1]);
+#else
                 const float2 t = *reinterpret_cast<const float2*>(cb + (unsigned)udm[0]);
+#endif
                 pv[0][2 * cp + e] = t.x; pv[1][2 * cp + e] = t.y;
             } else {
 #pragma unroll
@@ -2674,7 +2679,11 @@ __global__ __launch_bounds__(256) void conv1_thin_kernel(ConvArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = c0 + u < C ? c0 + u : C - 1;
-            v[u] = *reinterpret_cast<const float4*>(xb + (long)c * HW);
+            // (a read-once stream: non-temporal loads measured 63.2 -> 56.9 us per launch on the decoder's 128^2 projection; the
+            //  same on the streaming 1x1 kernel's input measured SLOWER, 66.2 -> 76.7 ms per 5 rollouts: LNS_CONV1_NT_LOADS)
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t tv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(xb + (long)c * HW));
+            v[u] = make_float4(tv[0], tv[1], tv[2], tv[3]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {

@@ -29,6 +29,13 @@ namespace lns {
 #ifndef LNS_CONV_STORE_AUX
 #define LNS_CONV_STORE_AUX 0
 #endif
+// non-temporal stores of the fused (3x3 + 1x1) and (1x1 + 1x1) kernels' outputs (A/B build knobs)
+#ifndef LNS_NTS_CONV3F
+#define LNS_NTS_CONV3F 0
+#endif
+#ifndef LNS_NTS_CONV1F
+#define LNS_NTS_CONV1F 0
+#endif
 #ifndef LNS_SAND_STORE_AUX
 #define LNS_SAND_STORE_AUX 0
 #endif
@@ -925,7 +932,7 @@ __device__ __forceinline__ void split2_pair_f16(float x, float y, unsigned& h, u
 // SHALF: the tile statistics go through the LDS scratch in two halves of 32 channels (17 KB instead of 34 KB; two more
 // barriers): the quad-phase upsampling conv (conv3_up2q.inc) keeps its whole split patch in LDS and has 18.5 KB of scratch.
 // NORES: the launch has no residual tensor (host-checked): the 32 registers of the residual tile are not reserved.
-template <int NT, bool FUSE2, int MT = 2, bool STATS = true, bool OCT = true, bool SHALF = false, bool NORES = false>
+template <int NT, bool FUSE2, int MT = 2, bool STATS = true, bool OCT = true, bool SHALF = false, bool NORES = false, bool NTS = false>
 __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_hi)[MT][NT], f32x16 (&acc_lo)[MT][NT],
                                                const int (&pix)[NT], int b, int ct, int kh, int l31, int tid, char* lds,
                                                float xinv, unsigned& am, const float* addv = nullptr, int sp_tile = -1, long long* ets = nullptr,
@@ -1206,7 +1213,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 for (int r = 0; r < 16; ++r) {
                     const int so = ((ct * TM + mt * 32 + (r & 3) + 8 * (r >> 2)) * HWo) * 4;     // uniform
                     const float v = acc[mt][nt][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, vo, so, LNS_CONV_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, vo, so, NTS ? 2 : LNS_CONV_STORE_AUX);
                     am = max(am, abs_bits(v));
                 }
         }
@@ -1241,7 +1248,7 @@ __device__ __forceinline__ void convb_epilogue(const ConvArgs& a, f32x16 (&acc_h
                 for (int r = 0; r < 16; ++r) {
                     const unsigned vr = vo + (unsigned)(((ct * TM + mt * 32 + (r & 3) + 8 * (r >> 2)) * HWo) * 4);
                     const float v = acc[mt][nt][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)vr, 0, LNS_CONV_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)vr, 0, NTS ? 2 : LNS_CONV_STORE_AUX);
                     am = max(am, vr < nb ? abs_bits(v) : 0u);
                     if (stats && !SHALF) sb[(mt * 32 + drow(r, kh)) * SROW + (tid >> 6) * 33 + l31] = v;     // (masked below)
                 }
@@ -1805,7 +1812,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bf16x3_kernel(ConvArgs a) {
     }
     unsigned am = 0u;
     LNS_TSTAMP(3)
-    convb_epilogue<NT, FUSE2, MT>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am,
+    convb_epilogue<NT, FUSE2, MT, true, true, false, false, (FUSE2 && LNS_NTS_CONV3F)>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am,
                                   (a.bias || a.badd) ? addv : nullptr, UP2 ? (ty * a.tiles_x + tx) * 4 + phase : -1 LNS_ETS_ARG,
                                   UP2 ? 4 : 1);
     LNS_TSTAMP(4)
@@ -2096,7 +2103,7 @@ __global__ __launch_bounds__(256, FUSE2 ? (CONVB1_MIN_WAVES > LNS_CONV1_FUSE2_WA
     }
     unsigned am = 0u;
     LNS_TSTAMP(3)
-    convb_epilogue<NT, FUSE2>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am, (a.bias || a.badd) ? addv : nullptr, -1 LNS_ETS_ARG);
+    convb_epilogue<NT, FUSE2, 2, true, true, false, false, (FUSE2 && LNS_NTS_CONV1F)>(a, acc_hi, acc_lo, pix, b, ct, kh, l31, tid, lds, xinv, am, (a.bias || a.badd) ? addv : nullptr, -1 LNS_ETS_ARG);
     LNS_TSTAMP(4)
     if (a.amax_out) amax_publish_block(a.amax_out, b, am, wmax);
     LNS_TS_DUMP

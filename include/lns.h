@@ -145,10 +145,10 @@ int lns_finalize_weights(lns_engine* e, int device);
  *   "track_nonfinite" 1: lns_check_finite also remembers the plan runs whose amax record has been reused since (the
  *                     earlier steps / decode groups of a rollout): one extra one-block launch per plan run (default 0)
  * One option selects an ARITHMETIC FORM (results differ at rounding level, ~2e-7 relative on the decoded field):
- *   "fa_fused"        2 (default; LNS_FA_FUSED): FABlock2D on 64 x 64 planes with 64 channels computes in_proj inside the
- *                     sandwich kernel (csrc/fa_fused.inc) -- the heads * dim_head plane tensor is never stored; 1: the same with a
- *                     single-buffered band image (same bits as 2, slower); 0: in_proj as its own 1x1 convolution, then the
- *                     sandwich.  Cached plans are rebuilt.
+ *   "fa_fused"        2 (default; LNS_FA_FUSED): FABlock2D on 64 x 64 planes with 64 channels and on 32 x 32 planes with 128
+ *                     channels computes in_proj inside the sandwich kernel (csrc/fa_fused.inc) -- the heads * dim_head plane tensor
+ *                     is never stored; 1 / 3: other forms of the 64 x 64 kernel (single-buffered band image / the generic kernel:
+ *                     same bits as 2, slower); 0: in_proj as its own 1x1 convolution, then the sandwich.  Cached plans are rebuilt.
  * Defaults come from LNS_DECODE_GROUP / LNS_DECODE_STREAMS / LNS_NO_OVERLAP / LNS_PROP_PRIORITY at lns_create().
  * Changing an option changes the workspace size: call lns_prepare() again. */
 int lns_set_option(lns_engine* e, const char* name, long value);

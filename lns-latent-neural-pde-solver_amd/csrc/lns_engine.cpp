@@ -816,7 +816,8 @@ struct Planner {
         // round 4: in_proj inside the sandwich kernel (fa_fused.inc) -- the plane tensor is only ever the sandwich's OUTPUT
         static const bool fused_off = getenv("LNS_FA_SANDWICH_FP32") != nullptr || getenv("LNS_CONV_FP32_MFMA") != nullptr ||
                                       getenv("LNS_CONV1_FP32_MFMA") != nullptr || getenv("LNS_FA_SANDWICH_BF16X3") != nullptr;
-        const bool fused_in = e->opt_fa_fused && !fused_off && fa_fused_fits(H, W, C, dh) && !e->packs[l.inproj].has_bias &&
+        static const bool no_small = getenv("LNS_FA_FUSED_NO_SMALL") != nullptr;      // A/B knob: only the 64 x 64 block
+        const bool fused_in = e->opt_fa_fused && !fused_off && fa_fused_fits(H, W, C, dh) && !(no_small && H < 64) && !e->packs[l.inproj].has_bias &&
                               e->packs[l.inproj].cout == heads * dh && xin.ss != 0 && xin.gn_bound > 0.0f;
         TRef uphi;
         size_t inproj_at = 0, gs_off = 0;
@@ -956,7 +957,7 @@ struct Planner {
             op.ff.out = as_ptr<float>(uphi.ptr);
             static const bool no_rev = getenv("LNS_FA_NO_REVERSE") != nullptr;
             op.ff.b_rev = no_rev ? 0 : 1;
-            op.ff.single_buffer = e->opt_fa_fused == 1 ? 1 : 0;
+            op.ff.single_buffer = e->opt_fa_fused == 1 ? 1 : (e->opt_fa_fused == 3 ? 2 : 0);
             {   // plane groups per block (scheduling only; "fa_fused_gpb" / LNS_FA_FUSED_GPB): by default all four groups of a
                 // head while the grid keeps two blocks per CU's worth of work
                 const int groups = dh / 16;
@@ -1922,7 +1923,7 @@ int lns_create(const lns_config* cfg, lns_engine** out) {
     if (getenv("LNS_NO_OVERLAP")) e->opt_overlap = 0;
     if (getenv("LNS_PROP_PRIORITY")) e->opt_prop_priority = 1;
     if (const char* v = getenv("LNS_FA_CHUNK_MB")) e->opt_fa_chunk_mb = atoi(v);
-    if (const char* v = getenv("LNS_FA_FUSED")) e->opt_fa_fused = std::min(2, std::max(0, atoi(v)));
+    if (const char* v = getenv("LNS_FA_FUSED")) e->opt_fa_fused = std::min(3, std::max(0, atoi(v)));
     if (const char* v = getenv("LNS_FA_FUSED_GPB")) e->opt_fa_fused_gpb = std::max(0, atoi(v));
     e->cfg.ae_prefix[sizeof(e->cfg.ae_prefix) - 1] = 0;
     e->cfg.prop_prefix[sizeof(e->cfg.prop_prefix) - 1] = 0;
@@ -1995,7 +1996,7 @@ int lns_set_option(lns_engine* e, const char* name, long value) {
     else if (n == "track_nonfinite") e->opt_track_nonfinite = value != 0;
     else if (n == "fa_fused" || n == "fa_fused_gpb") {
         if (n == "fa_fused_gpb" && (value < 0 || value > 64)) return LNS_EINVAL;
-        if (n == "fa_fused" && (value < 0 || value > 2)) return LNS_EINVAL;
+        if (n == "fa_fused" && (value < 0 || value > 3)) return LNS_EINVAL;
         const bool changed = n == "fa_fused" ? e->opt_fa_fused != (int)value : e->opt_fa_fused_gpb != (int)value;
         if (changed) {                                  // a planning rule of the decoder / encoder: cached plans are rebuilt
             DeviceGuard dg(e);

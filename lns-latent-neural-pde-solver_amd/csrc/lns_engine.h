@@ -169,7 +169,8 @@ struct lns_engine {
     int opt_fa_chunk_mb = 0;
     // FABlock2D at 64 x 64 planes, 64 channels: in_proj computed inside the sandwich kernel (fa_fused.inc) instead of written to
     // and read from HBM as a heads * dim_head plane tensor.  A planning rule ("fa_fused" option / LNS_FA_FUSED).
-    int opt_fa_fused = 2;          // 0: off, 1: single-buffered kernel, 2: double-buffered kernel (default)
+    int opt_fa_fused = 2;          // 0: off, 1: single-buffered kernel, 2: double-buffered kernel (default), 3: the generic kernel
+                                   // for the 64 x 64 block as well (tests); the 32 x 32 block (128 channels) uses the generic one for 1..3
     int opt_fa_fused_gpb = 0;      // plane groups (of 16) per block of the fused kernel; 0 = automatic (scheduling only)
     // what the last top-level call ran, for lns_check_finite: (plan kind, plan key, arena offset inside the caller's
     // workspace) -- no pointers into the plan caches or the workspace, which the caller may drop at any time -- plus

@@ -5104,6 +5104,9 @@ hipError_t init_kernels() {
 #undef LNS_SET_SWF
     LNS_SET_LDS((fa_fused_kernel<2>))
     LNS_SET_LDS((fa_fused2_kernel<2>))
+    LNS_SET_LDS((fa_fused_g_kernel<2, 2, 2>))
+    LNS_SET_LDS((fa_fused_g_kernel<4, 1, 1>))
+    LNS_SET_LDS((fa_fused_g_kernel<2, 1, 1>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, true>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 1, false>))
     LNS_SET_LDS((fa_sandwich_kernel<1, 2, true>))

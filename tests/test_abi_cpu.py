@@ -198,6 +198,6 @@ def test_set_option_validates_names_and_ranges():
     e.set_option("fa_fused", 2)
     e.set_option("fa_fused_gpb", 2)
     e.set_option("fa_fused_gpb", 0)
-    for bad in (("decode_group", 99), ("decode_streams", 0), ("no_such_option", 1), ("fa_chunk_mb", -1), ("fa_fused_gpb", -1), ("fa_fused", 3)):
+    for bad in (("decode_group", 99), ("decode_streams", 0), ("no_such_option", 1), ("fa_chunk_mb", -1), ("fa_fused_gpb", -1), ("fa_fused", 4)):
         with pytest.raises(_lib.LnsError):
             e.set_option(*bad)

@@ -670,7 +670,8 @@ def test_overlapped_rollout_equals_single_stream():
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [3, 16])
 def test_fablock_in_proj_inside_the_sandwich(B):
-    """FABlock2D at 64 x 64 planes: in_proj computed inside the sandwich kernel (csrc/fa_fused.inc, the default) against the
+    """FABlock2D at 64 x 64 planes (64 channels) and 32 x 32 planes (128 channels): in_proj computed inside the sandwich kernel
+    (csrc/fa_fused.inc, the default) against the
     three-kernel form (in_proj convolution -> sandwich -> to_out) on the same latents: rounding-level agreement of the decoded
     fields, both within the oracle's tolerance; the plane groups a block walks (1, 2, 4) and the batch-dependent block order
     (B % 8 == 0 or not) never change a bit."""
@@ -689,8 +690,9 @@ def test_fablock_in_proj_inside_the_sandwich(B):
         eng.set_option("fa_fused", 2)
         yf = eng.decode(z).clone()
         assert torch.isfinite(yf).all()
-        eng.set_option("fa_fused", 1)           # the single-buffered form of the kernel: the same arithmetic
-        assert torch.equal(eng.decode(z), yf)
+        for form in (1, 3):                     # the single-buffered and the generic form of the 64 x 64 kernel: the same arithmetic
+            eng.set_option("fa_fused", form)
+            assert torch.equal(eng.decode(z), yf), form
         eng.set_option("fa_fused", 2)
         assert rel_l2(yf.cpu().numpy(), y3.cpu().numpy()) < 1e-6
         assert not torch.equal(yf, y3)          # (the fused form really ran: another summation order)
